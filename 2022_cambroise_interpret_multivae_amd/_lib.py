@@ -1,0 +1,198 @@
+"""ctypes binding of libmopoe_hip.so (the C ABI of include/mopoe_hip.h).
+
+The library is the product: there is no PyTorch / CPU fallback.  If the shared
+object is missing or exports the wrong ABI this module raises at import time.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads the ROCm runtime the library binds to)
+
+MAX_MODS = 5
+MAX_SUBSETS = 31
+MAX_JOBS = 10
+HIDDEN = 256
+ROWS = 16
+ABI_VERSION = 1
+
+SUB_POE, SUB_POE_PRIOR, SUB_SLICES = 0, 1, 2
+JOINT_MIXTURE, JOINT_MEAN, JOINT_EXPERT = 0, 1, 2
+
+STAT_TOTAL_LOSS = 0
+STAT_JOINT_DIV = 1
+STAT_KLD_SUBSET = 2
+STAT_KLD_STYLE = 2 + MAX_SUBSETS
+STAT_NLL = STAT_KLD_STYLE + MAX_MODS
+NUM_STATS = STAT_NLL + MAX_JOBS
+
+_i32 = C.c_int32
+_u8 = C.c_uint8
+_f32 = C.c_float
+_ptr = C.c_void_p
+
+
+class Model(C.Structure):
+    _fields_ = [
+        ("num_mods", _i32),
+        ("class_dim", _i32),
+        ("input_dim", _i32 * MAX_MODS),
+        ("style_dim", _i32 * MAX_MODS),
+        ("learn_output_scale", _i32),
+        ("off_w1", _i32 * MAX_MODS),
+        ("off_b1", _i32 * MAX_MODS),
+        ("off_wh", _i32 * MAX_MODS),
+        ("off_bh", _i32 * MAX_MODS),
+        ("off_wd", _i32 * MAX_MODS),
+        ("off_bd", _i32 * MAX_MODS),
+        ("off_lvo", _i32 * MAX_MODS),
+        ("num_floats", _i32),
+    ]
+
+
+class Step(C.Structure):
+    _fields_ = [
+        ("n", _i32),
+        ("present_mask", _i32),
+        ("sample", _i32),
+        ("joint_mode", _i32),
+        ("expert_subset", _i32),
+        ("backward", _i32),
+        ("num_subsets", _i32),
+        ("sub_mask", _u8 * MAX_SUBSETS),
+        ("sub_avail", _u8 * MAX_SUBSETS),
+        ("sub_kind", _u8 * MAX_SUBSETS),
+        ("sub_members", (_u8 * MAX_MODS) * MAX_SUBSETS),
+        ("sub_f", _i32 * MAX_SUBSETS),
+        ("sub_kl_coef", _f32 * MAX_SUBSETS),
+        ("num_comp", _i32),
+        ("comp_sub", _u8 * MAX_SUBSETS),
+        ("comp_f", _i32),
+        ("comp_w", _f32 * MAX_SUBSETS),
+        ("style_kl_coef", _f32 * MAX_MODS),
+        ("num_jobs", _i32),
+        ("job_mod", _u8 * MAX_JOBS),
+        ("job_slot", _u8 * MAX_JOBS),
+        ("job_src", C.c_int8 * MAX_JOBS),
+        ("job_stream", _u8 * MAX_JOBS),
+        ("job_nll_coef", _f32 * MAX_JOBS),
+        ("job_eps_content", _ptr * MAX_JOBS),
+        ("job_eps_style", _ptr * MAX_JOBS),
+        ("seed", C.c_uint64),
+    ]
+
+
+class Buffers(C.Structure):
+    _fields_ = [
+        ("params", _ptr),
+        ("grads", _ptr),
+        ("exp_avg", _ptr),
+        ("exp_avg_sq", _ptr),
+        ("counters", _ptr),
+        ("x", _ptr * MAX_MODS),
+        ("row_index", _ptr),
+        ("hidden", _ptr * MAX_MODS),
+        ("heads", _ptr * MAX_MODS),
+        ("subsets_mu", _ptr),
+        ("subsets_logvar", _ptr),
+        ("joint_mu", _ptr),
+        ("joint_logvar", _ptr),
+        ("z", _ptr * MAX_MODS),
+        ("loc", _ptr * MAX_MODS),
+        ("stats", _ptr),
+        ("g_xhat", _ptr * MAX_MODS),
+        ("g_heads", _ptr * MAX_MODS),
+        ("g_pre", _ptr * MAX_MODS),
+        ("partials", _ptr),
+    ]
+
+
+class Adam(C.Structure):
+    _fields_ = [("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32)]
+
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                        "libmopoe_hip.so")
+
+# every symbol include/mopoe_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mopoe_abi_version": (C.c_int, []),
+    "mopoe_last_error": (C.c_char_p, []),
+    "mopoe_sizeof": (C.c_int, [C.c_int]),
+    "mopoe_model_layout": (C.c_int, [C.POINTER(Model)]),
+    "mopoe_ldz": (C.c_int, [C.POINTER(Model), C.c_int]),
+    "mopoe_partials_stride": (C.c_int, [C.POINTER(Model)]),
+    "mopoe_latent_lds_bytes": (C.c_int, [C.POINTER(Model), C.POINTER(Step)]),
+    "mopoe_forward": (C.c_int, [C.POINTER(Model), C.POINTER(Step),
+                                C.POINTER(Buffers), _ptr]),
+    "mopoe_train_step": (C.c_int, [C.POINTER(Model), C.POINTER(Step),
+                                   C.POINTER(Buffers), C.POINTER(Adam), _ptr]),
+    "mopoe_adam_step": (C.c_int, [C.POINTER(Model), _i32, C.POINTER(Buffers),
+                                  C.POINTER(Adam), _f32, _ptr]),
+    "mopoe_linear": (C.c_int, [_ptr, _i32, _i32, _ptr, _ptr, _i32, _i32, _ptr,
+                               _ptr]),
+    "mopoe_poe": (C.c_int, [_ptr, _ptr, _i32, C.c_int64, _f32, _ptr, _ptr,
+                            _ptr]),
+    "mopoe_kl_divergence": (C.c_int, [_ptr, _ptr, C.c_int64, _f32, _ptr, _ptr,
+                                      _ptr]),
+    "mopoe_reparameterize": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64,
+                                       C.c_uint64, C.c_uint64, _ptr, _ptr]),
+    "mopoe_mixture_select": (C.c_int, [_ptr, _ptr, _i32, _i32, _i32, _ptr,
+                                       _ptr, _ptr, _ptr]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libmopoe_hip.so is missing (%s): build it with "
+            "`make -C 2022_cambroise_interpret_multivae_amd/csrc` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`. There is "
+            "no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is absent
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.mopoe_abi_version() != ABI_VERSION:
+        raise ImportError("libmopoe_hip.so ABI %d != binding ABI %d"
+                          % (lib.mopoe_abi_version(), ABI_VERSION))
+    mirrors = [C.sizeof(Model), C.sizeof(Step), C.sizeof(Buffers),
+               C.sizeof(Adam), Step.job_eps_content.offset,
+               Step.comp_w.offset, Buffers.partials.offset,
+               Model.num_floats.offset]
+    for which, mine in enumerate(mirrors):
+        if lib.mopoe_sizeof(which) != mine:
+            raise ImportError("ctypes mirror %d disagrees with the C struct "
+                              "(%d vs %d)" % (which, mine,
+                                              lib.mopoe_sizeof(which)))
+    return lib
+
+
+lib = _load()
+
+
+class MopoeError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MopoeError("%s failed (%d): %s" % (
+            what, rc, lib.mopoe_last_error().decode("utf-8", "replace")))
+
+
+def require_gpu(t=None):
+    """The product path runs on the MI355X only."""
+    if not torch.cuda.is_available():
+        raise MopoeError("no HIP device visible: the MoPoE hot path has no "
+                         "CPU fallback")
+    if t is not None and not t.is_cuda:
+        raise MopoeError("expected a device tensor, got %s" % t.device)
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())

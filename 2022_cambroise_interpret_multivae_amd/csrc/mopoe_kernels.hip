@@ -1,0 +1,1322 @@
+// mopoe_kernels.hip -- hand-written gfx950 kernels of the MoPoE-VAE training
+// step and the C ABI declared in include/mopoe_hip.h.
+//
+// One training step = three launches on the caller's stream:
+//   k_enc_hidden   h_m = relu(x_m W1_m^T + b1_m)            (MFMA, grid over
+//                  row tiles x hidden column groups x modalities)
+//   k_latent       per 16-row tile, everything that is per-sample: encoder
+//                  heads (MFMA), powerset-of-experts fusion + KL + mixture
+//                  selection + reparameterisation (VALU, wave reductions),
+//                  decoder + Gaussian NLL (MFMA + epilogue) and the whole
+//                  data-gradient chain back to the pre-ReLU gradient
+//   k_wgrad        all weight/bias gradients as reductions over the batch
+//                  (MFMA), with the Adam update fused into the epilogue when
+//                  there is no cross-rank all-reduce in between
+// The math follows SURVEY.md Appendix A; reference file:line citations are in
+// include/mopoe_hip.h and DESIGN.md.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "mopoe_common.h"
+
+namespace {
+
+constexpr int kLatentThreads = 512;
+constexpr int kLatentWaves = kLatentThreads / kWave;
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+constexpr float kPoeEps = 1e-8f;
+
+struct KArgs {
+    mopoe_model mdl;
+    mopoe_step st;
+    mopoe_buffers buf;
+    LatentLds lds;  // carve-up of k_latent's LDS, computed on the host
+};
+static_assert(sizeof(KArgs) <= 3500, "kernel argument block too large");
+
+DEV int src_row(const mopoe_buffers& buf, int gn) {
+    return buf.row_index ? buf.row_index[gn] : gn;
+}
+
+// ---------------------------------------------------------------------------
+// k_linear: grouped Y_g[n, j] = act(sum_k X_g[n, k] W_g[j, k] + b_g[j]).
+// grid = (max column groups of 64, row tiles, groups), block = 256 (4 waves).
+// The training step uses it once, grouped over the present modalities, for
+// the encoder's hidden layer h_m = relu(x_m W1_m^T + b1_m).  The 16 x K input
+// tile is staged in LDS with coalesced 16-byte loads over the (batch x
+// feature) layout and shared by the four waves; each wave owns one 16 x 16
+// output tile and streams its 16 rows of W straight from L2 into registers.
+// ---------------------------------------------------------------------------
+struct LinGroup {
+    const float* X;        // (rows, K), row stride ldx
+    const int32_t* rows;   // optional gather index (n) or nullptr
+    const float* W;        // (ncols, K) row-major
+    const float* b;        // (ncols) or nullptr
+    float* Y;              // (n, ncols), row stride ldy
+    int32_t K, ldx, ncols, ldy, relu;
+};
+
+struct LinArgs {
+    int32_t n;
+    int32_t ngroups;
+    int32_t* bump;         // counter incremented once per launch, or nullptr
+    LinGroup g[MOPOE_MAX_MODS];
+};
+
+__global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.n;
+    if (a.bump && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
+        *a.bump += 1;  // training step number t (read by Adam and Philox)
+    const LinGroup& g = a.g[blockIdx.z];
+    if ((int)blockIdx.x * 64 >= g.ncols) return;
+    const int K = g.K;
+    const float* __restrict__ X = g.X;
+    const bool vecx = (g.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const bool vecw = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.W) & 15) == 0);
+    const int n0 = blockIdx.y * kRows;
+    const int j0 = (blockIdx.x * 4 + wave) * 16;
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kc0 = 0; kc0 < K; kc0 += kEncKChunk) {
+        const int Kc = min(kEncKChunk, K - kc0);
+        const int Kp = round_up(Kc, 16);
+        const int ldx = Kp + 4;
+        const int q4 = Kp / 4;
+        if (kc0 > 0) __syncthreads();
+        for (int s = tid; s < kRows * q4; s += blockDim.x) {
+            const int r = s / q4, k = (s - r * q4) * 4;
+            const int gn = n0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gn < N) {
+                const int xr = g.rows ? g.rows[gn] : gn;
+                const float* p = X + (size_t)xr * g.ldx + kc0 + k;
+                if (vecx && k + 3 < Kc) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+                    if (k < Kc) v[0] = p[0];
+                    if (k + 1 < Kc) v[1] = p[1];
+                    if (k + 2 < Kc) v[2] = p[2];
+                    if (k + 3 < Kc) v[3] = p[3];
+                }
+            }
+            *reinterpret_cast<f32x4*>(lds + r * ldx + k) = v;
+        }
+        __syncthreads();
+        if (j0 < g.ncols)
+            acc = tile_gemm<true>(acc, lds, ldx, g.W + kc0, K, g.ncols, Kc, j0, 0, Kp, lane,
+                                  vecw);
+    }
+    const int col = j0 + (lane & 15);
+    if (col >= g.ncols) return;
+    const float bias = g.b ? g.b[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gn = n0 + 4 * (lane >> 4) + r;
+        if (gn < N) {
+            const float v = acc[r] + bias;
+            g.Y[(size_t)gn * g.ldy + col] = g.relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_latent helpers
+// ---------------------------------------------------------------------------
+struct Experts {  // unimodal content posteriors of one (row, latent dim)
+    float mu[MOPOE_MAX_MODS];
+    float lv[MOPOE_MAX_MODS];
+    float T[MOPOE_MAX_MODS];  // precision 1/(exp(lv)+eps)  (mm_div.py:14-16)
+};
+
+DEV float pick(const float (&v)[MOPOE_MAX_MODS], int idx) {
+    float r = v[0];
+#pragma unroll
+    for (int i = 1; i < MOPOE_MAX_MODS; ++i) r = (idx == i) ? v[i] : r;
+    return r;
+}
+
+// member of a SLICES subset that owns batch row gn (utils/utils.py:63-85)
+DEV int slice_member(const mopoe_step& st, int s, int gn) {
+    const int E = __popc((unsigned)st.sub_mask[s]);
+    const int f = st.sub_f[s];
+    const int j = f > 0 ? min(gn / f, E - 1) : E - 1;
+    return st.sub_members[s][j];
+}
+
+// (mu, logvar) of subset s at one (row, dim): mm_div.poe (mm_div.py:13-20)
+// behind BaseMMVae.poe_fusion (BaseMMVae.py:109-122), or moe_fusion (:96-106).
+DEV void subset_dist(const mopoe_step& st, int s, const Experts& e, int gn, float& mu_s,
+                     float& lv_s, float& tsum_out) {
+    const int kind = st.sub_kind[s];
+    if (kind == MOPOE_SUB_SLICES) {
+        const int ms = slice_member(st, s, gn);
+        mu_s = pick(e.mu, ms);
+        lv_s = pick(e.lv, ms);
+        tsum_out = 1.f;
+        return;
+    }
+    const unsigned mask = st.sub_mask[s];
+    float musum = 0.f, tsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MOPOE_MAX_MODS; ++i)
+        if ((mask >> i) & 1) {
+            musum += e.mu[i] * e.T[i];
+            tsum += e.T[i];
+        }
+    if (kind == MOPOE_SUB_POE_PRIOR) {
+        const float tp = 1.f / (1.f + kPoeEps);  // exp(0) + eps
+        musum += 0.f * tp;
+        tsum += tp;
+    }
+    mu_s = musum / tsum;
+    lv_s = logf(1.f / tsum);
+    tsum_out = tsum;
+}
+
+DEV int joint_component(const mopoe_step& st, int gn) {
+    const int K = st.num_comp;
+    return st.comp_f > 0 ? min(gn / st.comp_f, K - 1) : K - 1;
+}
+
+DEV float job_eps_content(const KArgs& a, int j, int gn, int d, uint32_t step) {
+    const float* p = a.st.job_eps_content[j];
+    if (p) return p[(size_t)gn * a.mdl.class_dim + d];
+    return philox_normal(a.st.seed, step, a.st.job_stream[j],
+                         (uint32_t)(gn * a.mdl.class_dim + d));
+}
+
+DEV float job_eps_style(const KArgs& a, int j, int gn, int d, uint32_t step) {
+    const float* p = a.st.job_eps_style[j];
+    const int sd = a.mdl.style_dim[a.st.job_mod[j]];
+    if (p) return p[(size_t)gn * sd + d];
+    return philox_normal(a.st.seed, step, 64u + (uint32_t)j, (uint32_t)(gn * sd + d));
+}
+
+// ---------------------------------------------------------------------------
+// k_latent: grid = row tiles, block = 512 (8 waves).  See file header.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kLatentThreads) void k_latent(const KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const mopoe_model& mdl = a.mdl;
+    const mopoe_step& st = a.st;
+    const mopoe_buffers& buf = a.buf;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = st.n, D = mdl.class_dim, M = mdl.num_mods;
+    const int n0 = blockIdx.x * kRows;
+    const float inv_n = 1.0f / (float)N;
+    const bool bwd = st.backward != 0;
+    const bool sample = st.sample != 0;
+    const uint32_t step_no = (uint32_t)buf.counters[0];
+    const float* __restrict__ P = buf.params;
+
+    const LatentLds& L = a.lds;
+    float* red = lds + L.red;
+
+    // ---- S0: hidden tiles -> LDS, zero the reduction scratch ---------------
+    for (int i = tid; i < kLatentWaves * kStatStride; i += kLatentThreads) red[i] = 0.f;
+    for (int m = 0; m < M; ++m) {
+        if (!((st.present_mask >> m) & 1)) continue;
+        const float* __restrict__ H = buf.hidden[m];
+        float* hs = lds + L.hs[m];
+        for (int s = tid; s < kRows * (kHid / 4); s += kLatentThreads) {
+            const int r = s / (kHid / 4), k = (s % (kHid / 4)) * 4;
+            const int gn = n0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gn < N) v = *reinterpret_cast<const f32x4*>(H + (size_t)gn * kHid + k);
+            *reinterpret_cast<f32x4*>(hs + r * kLdH + k) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- S1: encoder heads [style_mu|style_lv|class_mu|class_lv] ----------
+    {
+        int u = wave;
+        int base = 0;
+        for (int m = 0; m < M; ++m) {
+            if (!((st.present_mask >> m) & 1)) continue;
+            const int nh = heads_dim(mdl, m), tiles = cdiv(nh, 16);
+            const int ldh = ld_heads_lds(mdl, m);
+            for (; u < base + tiles; u += kLatentWaves) {
+                const int j0 = (u - base) * 16;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = tile_gemm<true>(acc, lds + L.hs[m], kLdH, P + mdl.off_wh[m], kHid,
+                                      nh, kHid, j0, 0, kHid, lane, true);
+                const int col = j0 + (lane & 15);
+                const float bias = col < nh ? P[mdl.off_bh[m] + col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * (lane >> 4) + r, gn = n0 + row;
+                    const float v = col < nh ? acc[r] + bias : 0.f;
+                    lds[L.heads[m] + row * ldh + col] = v;
+                    if (col < nh && gn < N) buf.heads[m][(size_t)gn * nh + col] = v;
+                }
+            }
+            base += tiles;
+        }
+    }
+    __syncthreads();
+
+    // ---- S2: subset fusion, KL, joint latent, reparameterisation ----------
+    for (int e0 = 0; e0 < kRows * D; e0 += kLatentThreads) {
+        const int e = e0 + tid;
+        const bool act = e < kRows * D;
+        const int row = act ? e / D : 0, d = act ? e - row * D : 0;
+        const int gn = n0 + row;
+        const bool valid = act && gn < N;
+        Experts ex;
+#pragma unroll
+        for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
+            ex.mu[m] = 0.f;
+            ex.lv[m] = 0.f;
+            ex.T[m] = 0.f;
+            if (m < M && ((st.present_mask >> m) & 1)) {
+                const float* hd = lds + L.heads[m] + row * ld_heads_lds(mdl, m) +
+                                  2 * mdl.style_dim[m];
+                ex.mu[m] = hd[d];
+                ex.lv[m] = hd[D + d];
+                ex.T[m] = 1.f / (expf(ex.lv[m]) + kPoeEps);
+            }
+        }
+        const int s_sel = st.comp_sub[joint_component(st, gn < N ? gn : 0)];
+        float jmu = 0.f, jlv = 0.f;
+        for (int s = 0; s < st.num_subsets; ++s) {
+            if (!st.sub_avail[s]) continue;
+            float mu_s, lv_s, tsum;
+            subset_dist(st, s, ex, gn, mu_s, lv_s, tsum);
+            if (valid) {
+                const size_t o = ((size_t)s * N + gn) * D + d;
+                buf.subsets_mu[o] = mu_s;
+                buf.subsets_logvar[o] = lv_s;
+            }
+            // kl_div.py:9: -0.5 * sum(1 - exp(lv) - mu^2 + lv); scaled at the end
+            const float t = valid ? (1.f - expf(lv_s) - mu_s * mu_s + lv_s) : 0.f;
+            const float ws = wave_sum(t);
+            if (lane == 0) red[wave * kStatStride + kPartKlSub + s] += ws;
+            if (st.joint_mode == MOPOE_JOINT_MIXTURE) {
+                if (s == s_sel) {
+                    jmu = mu_s;
+                    jlv = lv_s;
+                }
+            } else if (st.joint_mode == MOPOE_JOINT_EXPERT) {
+                if (s == st.expert_subset) {
+                    jmu = mu_s;
+                    jlv = lv_s;
+                }
+            }
+        }
+        if (st.joint_mode == MOPOE_JOINT_MEAN) {  // BaseMMVae.py:229
+            for (int k = 0; k < st.num_comp; ++k) {
+                float mu_s, lv_s, tsum;
+                subset_dist(st, st.comp_sub[k], ex, gn, mu_s, lv_s, tsum);
+                jmu += mu_s;
+                jlv += lv_s;
+            }
+            jmu /= (float)st.num_comp;
+            jlv /= (float)st.num_comp;
+        }
+        if (valid) {
+            buf.joint_mu[(size_t)gn * D + d] = jmu;
+            buf.joint_logvar[(size_t)gn * D + d] = jlv;
+        }
+        if (act) {
+            for (int j = 0; j < st.num_jobs; ++j) {
+                const int m = st.job_mod[j];
+                float zmu = jmu, zlv = jlv;
+                if (st.job_src[j] >= 0) {
+                    float tsum;
+                    subset_dist(st, st.job_src[j], ex, gn, zmu, zlv, tsum);
+                }
+                float z = zmu;
+                if (sample && valid)  // BaseMMVae.py:37-40: eps * std + mu
+                    z = job_eps_content(a, j, gn, d, step_no) * expf(0.5f * zlv) + zmu;
+                const int c = mdl.style_dim[m] + d;
+                lds[L.zj[j] + row * ld_z_lds(mdl, m) + c] = z;
+                if (valid)
+                    buf.z[m][((size_t)st.job_slot[j] * N + gn) * ldz_glb(mdl, m) + c] = z;
+            }
+        }
+    }
+    // style latents and their KL
+    for (int m = 0; m < M; ++m) {
+        if (!((st.present_mask >> m) & 1)) continue;
+        const int sd = mdl.style_dim[m];
+        const int ldh = ld_heads_lds(mdl, m);
+        for (int e0 = 0; e0 < kRows * sd; e0 += kLatentThreads) {
+            const int e = e0 + tid;
+            const bool act = e < kRows * sd;
+            const int row = act ? e / sd : 0, d = act ? e - row * sd : 0;
+            const int gn = n0 + row;
+            const bool valid = act && gn < N;
+            const float smu = lds[L.heads[m] + row * ldh + d];
+            const float slv = lds[L.heads[m] + row * ldh + sd + d];
+            const float t = valid ? (1.f - expf(slv) - smu * smu + slv) : 0.f;
+            const float ws = wave_sum(t);
+            if (lane == 0) red[wave * kStatStride + kPartKlStyle + m] += ws;
+            if (act) {
+                for (int j = 0; j < st.num_jobs; ++j) {
+                    if (st.job_mod[j] != m) continue;
+                    float z = smu;
+                    if (sample && valid)
+                        z = job_eps_style(a, j, gn, d, step_no) * expf(0.5f * slv) + smu;
+                    lds[L.zj[j] + row * ld_z_lds(mdl, m) + d] = z;
+                    if (valid)
+                        buf.z[m][((size_t)st.job_slot[j] * N + gn) * ldz_glb(mdl, m) + d] = z;
+                }
+            }
+        }
+    }
+    // zero the K padding of every z tile (A operand of the decoder GEMM)
+    for (int j = 0; j < st.num_jobs; ++j) {
+        const int m = st.job_mod[j];
+        const int zd = z_dim(mdl, m), zp = round_up(zd, 16) - zd, ldzs = ld_z_lds(mdl, m);
+        for (int e = tid; e < kRows * zp; e += kLatentThreads)
+            lds[L.zj[j] + (e / zp) * ldzs + zd + (e % zp)] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- S3/S4: decoder + NLL, then d loss / d z, one pass at a time -------
+    // (joint_elbo / moe: a single pass over all present modalities; poe: the
+    // joint pass followed by one unimodal pass per present modality,
+    // run_epochs.py:104-128)
+    float* part = buf.partials + (size_t)blockIdx.x * partials_stride(mdl);
+    for (int jb = 0; jb < st.num_jobs;) {
+        int je = jb + 1;
+        while (je < st.num_jobs && st.job_stream[je] == st.job_stream[jb]) ++je;
+        // S3: x_hat = z Wd^T + bd; Gaussian NLL epilogue (modality.py:42-45)
+        {
+            int u = wave, base = 0;
+            for (int j = jb; j < je; ++j) {
+                const int m = st.job_mod[j];
+                const int dm = mdl.input_dim[m], zd = z_dim(mdl, m);
+                const int tiles = cdiv(dm, 16), ldxs = ld_x_lds(mdl, m);
+                const float* __restrict__ X = buf.x[m];
+                const float coef = st.job_nll_coef[j] * inv_n;
+                const size_t rbase = (size_t)st.job_slot[j] * N;
+                for (; u < base + tiles; u += kLatentWaves) {
+                    const int j0 = (u - base) * 16;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = tile_gemm<true>(acc, lds + L.zj[j], ld_z_lds(mdl, m),
+                                          P + mdl.off_wd[m], zd, dm, zd, j0, 0,
+                                          round_up(zd, 16), lane, zd % 4 == 0);
+                    const int col = j0 + (lane & 15);
+                    const bool colv = col < dm;
+                    const float bias = colv ? P[mdl.off_bd[m] + col] : 0.f;
+                    const float lvo = colv ? P[mdl.off_lvo[m] + col] : 0.f;
+                    const float inv_var = expf(-lvo);
+                    float nll = 0.f, glv = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 4 * (lane >> 4) + r, gn = n0 + row;
+                        const bool valid = colv && gn < N;
+                        float g = 0.f;
+                        if (valid) {
+                            const float xhat = acc[r] + bias;
+                            const float x = X[(size_t)src_row(buf, gn) * dm + col];
+                            const float diff = x - xhat;
+                            const float q = 0.5f * diff * diff * inv_var;
+                            nll += q + 0.5f * lvo + kHalfLog2Pi;
+                            glv += 0.5f - q;
+                            g = -diff * inv_var * coef;
+                            buf.loc[m][(rbase + gn) * dm + col] = xhat;
+                            if (bwd) buf.g_xhat[m][(rbase + gn) * dm + col] = g;
+                        }
+                        if (bwd) lds[L.gx[m] + row * ldxs + col] = g;
+                    }
+                    const float ws = wave_sum(nll);
+                    if (lane == 0) red[wave * kStatStride + kPartNll + j] += ws;
+                    if (bwd) {
+                        glv += __shfl_xor(glv, 16, kWave);
+                        glv += __shfl_xor(glv, 32, kWave);
+                        if (lane < 16 && colv) {
+                            float* p = part + lvo_part_off(mdl, m) + col;
+                            const float v = glv * coef;
+                            *p = (st.job_slot[j] == 0) ? v : *p + v;
+                        }
+                    }
+                }
+                base += tiles;
+            }
+        }
+        if (!bwd) {
+            jb = je;
+            continue;
+        }
+        __syncthreads();
+        // S4: g_z = g_xhat Wd, K = d_m split in kGzChunks partial slabs
+        {
+            int u = wave, base = 0, zoff = 0;
+            for (int j = jb; j < je; ++j) {
+                const int m = st.job_mod[j];
+                const int dm = mdl.input_dim[m], zd = z_dim(mdl, m);
+                const int ct = cdiv(zd, 16), Kp = round_up(dm, 16);
+                const int kch = round_up(cdiv(Kp, kGzChunks), 16);
+                const int units = ct * kGzChunks;
+                for (; u < base + units; u += kLatentWaves) {
+                    const int t = (u - base) / kGzChunks, c = (u - base) % kGzChunks;
+                    const int kbeg = min(c * kch, Kp), kend = min(kbeg + kch, Kp);
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = tile_gemm<false>(acc, lds + L.gx[m], ld_x_lds(mdl, m),
+                                           P + mdl.off_wd[m], zd, zd, dm, t * 16, kbeg,
+                                           kend, lane, false);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 4 * (lane >> 4) + r;
+                        lds[L.gzp + (c * kRows + row) * L.ld_gzp + zoff + t * 16 +
+                            (lane & 15)] = acc[r];
+                    }
+                }
+                base += units;
+                zoff += round_up(zd, 16);
+            }
+        }
+        __syncthreads();
+        {
+            int zoff = 0;
+            for (int j = jb; j < je; ++j) {
+                const int m = st.job_mod[j];
+                const int zp = round_up(z_dim(mdl, m), 16), ldzs = ld_z_lds(mdl, m);
+                for (int e = tid; e < kRows * zp; e += kLatentThreads) {
+                    const int row = e / zp, c = e - row * zp;
+                    float s = 0.f;
+#pragma unroll
+                    for (int k = 0; k < kGzChunks; ++k)
+                        s += lds[L.gzp + (k * kRows + row) * L.ld_gzp + zoff + c];
+                    lds[L.gzj[j] + row * ldzs + c] = s;
+                }
+                zoff += zp;
+            }
+        }
+        __syncthreads();
+        jb = je;
+    }
+
+    if (bwd) {
+        // ---- S5: backward of reparameterisation, KL and subset fusion ------
+        for (int e0 = 0; e0 < kRows * D; e0 += kLatentThreads) {
+            const int e = e0 + tid;
+            if (e >= kRows * D) break;
+            const int row = e / D, d = e - row * D;
+            const int gn = n0 + row;
+            const bool valid = gn < N;
+            Experts ex;
+            float gmu[MOPOE_MAX_MODS], glv[MOPOE_MAX_MODS];
+#pragma unroll
+            for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
+                ex.mu[m] = ex.lv[m] = ex.T[m] = 0.f;
+                gmu[m] = glv[m] = 0.f;
+                if (m < M && ((st.present_mask >> m) & 1)) {
+                    const float* hd = lds + L.heads[m] + row * ld_heads_lds(mdl, m) +
+                                      2 * mdl.style_dim[m];
+                    ex.mu[m] = hd[d];
+                    ex.lv[m] = hd[D + d];
+                    ex.T[m] = 1.f / (expf(ex.lv[m]) + kPoeEps);
+                }
+            }
+            const int s_sel = st.comp_sub[joint_component(st, valid ? gn : 0)];
+            if (valid) {
+                for (int s = 0; s < st.num_subsets; ++s) {
+                    if (!st.sub_avail[s]) continue;
+                    // does anything flow into this subset?
+                    float kc = st.sub_kl_coef[s];
+                    bool used = kc != 0.f;
+                    for (int j = 0; j < st.num_jobs; ++j)
+                        used = used || (st.job_src[j] < 0 ? s == s_sel : st.job_src[j] == s);
+                    if (!used) continue;
+                    float mu_s, lv_s, tsum;
+                    subset_dist(st, s, ex, gn, mu_s, lv_s, tsum);
+                    // KL(N(mu, e^lv) || N(0,1)) / N, weighted (kl_div.py:9-13)
+                    float g_mu = kc * mu_s * inv_n;
+                    float g_lv = kc * 0.5f * (expf(lv_s) - 1.f) * inv_n;
+                    for (int j = 0; j < st.num_jobs; ++j) {
+                        const bool hit = st.job_src[j] < 0 ? s == s_sel : st.job_src[j] == s;
+                        if (!hit) continue;
+                        const int m = st.job_mod[j];
+                        const float gz =
+                            lds[L.gzj[j] + row * ld_z_lds(mdl, m) + mdl.style_dim[m] + d];
+                        g_mu += gz;
+                        if (sample)
+                            g_lv += gz * job_eps_content(a, j, gn, d, step_no) * 0.5f *
+                                    expf(0.5f * lv_s);
+                    }
+                    if (st.sub_kind[s] == MOPOE_SUB_SLICES) {
+                        const int ms = slice_member(st, s, gn);
+#pragma unroll
+                        for (int m = 0; m < MOPOE_MAX_MODS; ++m)
+                            if (m == ms) {
+                                gmu[m] += g_mu;
+                                glv[m] += g_lv;
+                            }
+                    } else {
+                        const unsigned mask = st.sub_mask[s];
+#pragma unroll
+                        for (int m = 0; m < MOPOE_MAX_MODS; ++m)
+                            if ((mask >> m) & 1) {
+                                gmu[m] += g_mu * ex.T[m] / tsum;
+                                const float gT = (g_mu * (ex.mu[m] - mu_s) - g_lv) / tsum;
+                                glv[m] += gT * (-ex.T[m] * ex.T[m] * expf(ex.lv[m]));
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
+                if (m < M && ((st.present_mask >> m) & 1)) {
+                    const int c = 2 * mdl.style_dim[m] + d;
+                    float* gh = lds + L.gheads[m] + row * ld_heads_lds(mdl, m);
+                    gh[c] = gmu[m];
+                    gh[c + D] = glv[m];
+                    if (valid) {
+                        float* o = buf.g_heads[m] + (size_t)gn * heads_dim(mdl, m);
+                        o[c] = gmu[m];
+                        o[c + D] = glv[m];
+                    }
+                }
+            }
+        }
+        for (int m = 0; m < M; ++m) {
+            if (!((st.present_mask >> m) & 1)) continue;
+            const int sd = mdl.style_dim[m], nh = heads_dim(mdl, m);
+            const int ldh = ld_heads_lds(mdl, m);
+            const float kc = st.style_kl_coef[m];
+            for (int e = tid; e < kRows * sd; e += kLatentThreads) {
+                const int row = e / sd, d = e - row * sd;
+                const int gn = n0 + row;
+                float g_mu = 0.f, g_lv = 0.f;
+                if (gn < N) {
+                    const float smu = lds[L.heads[m] + row * ldh + d];
+                    const float slv = lds[L.heads[m] + row * ldh + sd + d];
+                    g_mu = kc * smu * inv_n;
+                    g_lv = kc * 0.5f * (expf(slv) - 1.f) * inv_n;
+                    for (int j = 0; j < st.num_jobs; ++j) {
+                        if (st.job_mod[j] != m) continue;
+                        const float gz = lds[L.gzj[j] + row * ld_z_lds(mdl, m) + d];
+                        g_mu += gz;
+                        if (sample)
+                            g_lv += gz * job_eps_style(a, j, gn, d, step_no) * 0.5f *
+                                    expf(0.5f * slv);
+                    }
+                    buf.g_heads[m][(size_t)gn * nh + d] = g_mu;
+                    buf.g_heads[m][(size_t)gn * nh + sd + d] = g_lv;
+                }
+                lds[L.gheads[m] + row * ldh + d] = g_mu;
+                lds[L.gheads[m] + row * ldh + sd + d] = g_lv;
+            }
+            const int pad = round_up(nh, 16) - nh;
+            for (int e = tid; e < kRows * pad; e += kLatentThreads)
+                lds[L.gheads[m] + (e / pad) * ldh + nh + (e % pad)] = 0.f;
+        }
+        __syncthreads();
+
+        // ---- S6: g_pre = (g_heads Wh) * [h > 0] ---------------------------
+        {
+            int u = wave, base = 0;
+            for (int m = 0; m < M; ++m) {
+                if (!((st.present_mask >> m) & 1)) continue;
+                const int nh = heads_dim(mdl, m);
+                const float* __restrict__ H = buf.hidden[m];
+                for (; u < base + kHid / 16; u += kLatentWaves) {
+                    const int j0 = (u - base) * 16;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = tile_gemm<false>(acc, lds + L.gheads[m], ld_heads_lds(mdl, m),
+                                           P + mdl.off_wh[m], kHid, kHid, nh, j0, 0,
+                                           round_up(nh, 16), lane, false);
+                    const int col = j0 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gn = n0 + 4 * (lane >> 4) + r;
+                        if (gn < N) {
+                            const float h = H[(size_t)gn * kHid + col];
+                            buf.g_pre[m][(size_t)gn * kHid + col] = h > 0.f ? acc[r] : 0.f;
+                        }
+                    }
+                }
+                base += kHid / 16;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < kNumPart) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < kLatentWaves; ++w) s += red[w * kStatStride + tid];
+        part[tid] = s;
+    }
+}
+
+// Scalars of the step from the row tiles' partial sums, in a fixed order
+// (run_epochs.py:89-128, mm_div.py:92-111, kl_div.py:7-14).  One block.
+DEV void finalize_stats(const KArgs& a, int tid) {
+    __shared__ float sums[kNumPart];
+    const mopoe_buffers& buf = a.buf;
+    const int tiles = cdiv(a.st.n, kRows);
+    const int stride = partials_stride(a.mdl);
+    if (tid < kNumPart) {
+        float s = 0.f;
+        for (int t = 0; t < tiles; ++t) s += buf.partials[(size_t)t * stride + tid];
+        sums[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const mopoe_step& st = a.st;
+        const float fn = (float)st.n;
+        float total = 0.f;
+        for (int s = 0; s < MOPOE_MAX_SUBSETS; ++s) {
+            float kld = 0.f;
+            if (s < st.num_subsets && st.sub_avail[s]) {
+                kld = -0.5f * sums[kPartKlSub + s] / fn;
+                total += st.sub_kl_coef[s] * kld;
+            }
+            buf.stats[MOPOE_STAT_KLD_SUBSET + s] = kld;
+        }
+        float jd = 0.f;
+        for (int k = 0; k < st.num_comp; ++k)
+            jd += st.comp_w[k] * (-0.5f * sums[kPartKlSub + st.comp_sub[k]] / fn);
+        buf.stats[MOPOE_STAT_JOINT_DIV] = jd;
+        for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
+            float kld = 0.f;
+            if (m < a.mdl.num_mods && ((st.present_mask >> m) & 1) && a.mdl.style_dim[m] > 0) {
+                kld = -0.5f * sums[kPartKlStyle + m] / fn;
+                total += st.style_kl_coef[m] * kld;
+            }
+            buf.stats[MOPOE_STAT_KLD_STYLE + m] = kld;
+        }
+        for (int j = 0; j < MOPOE_MAX_JOBS; ++j) {
+            float nll = 0.f;
+            if (j < st.num_jobs) {
+                nll = sums[kPartNll + j] / fn;
+                total += st.job_nll_coef[j] * nll;
+            }
+            buf.stats[MOPOE_STAT_NLL + j] = nll;
+        }
+        buf.stats[MOPOE_STAT_TOTAL_LOSS] = total;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_wgrad: every weight / bias gradient is G^T X reduced over the batch rows.
+//   W1_m: G = g_pre_m (n,256)      X = x_m   (n,d_m)   (+ bias column)
+//   Wh_m: G = g_heads_m (n,nh_m)   X = h_m   (n,256)   (+ bias column)
+//   Wd_m: G = g_xhat_m (R_m,d_m)   X = z_m   (R_m,zd)  (+ bias column)
+// One workgroup (4 waves) per 16x16 output tile; the waves split the row
+// range and are summed in fixed order through LDS (deterministic).  The bias
+// gradient is the column of an implicit all-ones feature appended to X.
+// Extra blocks reduce the decoder-logvar partials and finalise the scalars.
+// With adam.lr != 0 the Adam update is applied in the epilogue.
+// ---------------------------------------------------------------------------
+struct WJob {
+    const float* G;
+    const float* X;
+    const int32_t* xrows;  // gather index for X rows or nullptr
+    int32_t ldg, gcols, ldx, xcols, R;
+    int32_t off_w, off_b;
+    int32_t tiles_j, tile_begin;
+};
+
+struct WArgs {
+    int32_t njobs;
+    int32_t total_tiles;   // GEMM tiles
+    int32_t lvo_blocks;    // blocks after the GEMM tiles
+    int32_t fuse_adam;
+    WJob jobs[3 * MOPOE_MAX_MODS];
+    int32_t lvo_block_begin[MOPOE_MAX_MODS + 1];
+    mopoe_adam adam;
+};
+
+struct AdamCoef {
+    float b1, b2, one_m_b1, one_m_b2, step_size, bc2_sqrt, eps;
+};
+
+DEV AdamCoef adam_coef(const mopoe_adam& ad, int t) {
+    // torch.optim.Adam (_single_tensor_adam): python-double scalars applied
+    // to float32 tensors
+    AdamCoef c;
+    const double b1 = (double)ad.beta1, b2 = (double)ad.beta2;
+    const double bc1 = 1.0 - pow(b1, (double)t);
+    const double bc2 = 1.0 - pow(b2, (double)t);
+    c.b1 = ad.beta1;
+    c.b2 = ad.beta2;
+    c.one_m_b1 = (float)(1.0 - b1);
+    c.one_m_b2 = (float)(1.0 - b2);
+    c.step_size = (float)((double)ad.lr / bc1);
+    c.bc2_sqrt = (float)sqrt(bc2);
+    c.eps = ad.eps;
+    return c;
+}
+
+DEV void adam_update(const AdamCoef& c, float g, float* p, float* m, float* v) {
+    const float m1 = *m + c.one_m_b1 * (g - *m);           // exp_avg.lerp_(g, 1-b1)
+    const float v1 = *v * c.b2 + (c.one_m_b2 * g) * g;     // mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = sqrtf(v1) / c.bc2_sqrt + c.eps;
+    *m = m1;
+    *v = v1;
+    *p = *p - c.step_size * (m1 / denom);                  // addcdiv_(m, denom, -step)
+}
+
+__global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
+    __shared__ f32x4 redacc[4][kWave];
+    const mopoe_buffers& buf = a.buf;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const bool fuse = w.fuse_adam != 0;
+    AdamCoef ac;
+    if (fuse) ac = adam_coef(w.adam, buf.counters[0]);
+
+    if (b < w.total_tiles) {
+        int ji = 0;
+        while (ji + 1 < w.njobs && b >= w.jobs[ji + 1].tile_begin) ++ji;
+        const WJob& job = w.jobs[ji];
+        const int t = b - job.tile_begin;
+        const int i0 = (t / job.tiles_j) * 16, j0 = (t % job.tiles_j) * 16;
+        const int R = job.R;
+        const int rq = round_up(cdiv(R, 4), 4);
+        const int rbeg = wave * rq, rend = min(rbeg + rq, R);
+        const int ci = i0 + (lane & 15), cj = j0 + (lane & 15), q = lane >> 4;
+        const bool iv = ci < job.gcols;
+        const bool jv = cj < job.xcols, jb = cj == job.xcols;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        for (int rb = rbeg; rb < rend; rb += 16) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int r = rb + 4 * s + q;
+                const bool rv = r < rend;
+                av[s] = (rv && iv) ? job.G[(size_t)r * job.ldg + ci] : 0.f;
+                float x = 0.f;
+                if (rv) {
+                    if (jv) {
+                        const int xr = job.xrows ? job.xrows[r] : r;
+                        x = job.X[(size_t)xr * job.ldx + cj];
+                    } else if (jb) {
+                        x = 1.f;
+                    }
+                }
+                bv[s] = x;
+            }
+            acc = mfma_16x16x4(av[0], bv[0], acc);
+            acc2 = mfma_16x16x4(av[1], bv[1], acc2);
+            acc = mfma_16x16x4(av[2], bv[2], acc);
+            acc2 = mfma_16x16x4(av[3], bv[3], acc2);
+        }
+        redacc[wave][lane] = acc + acc2;
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 g = redacc[0][lane];
+            g += redacc[1][lane];
+            g += redacc[2][lane];
+            g += redacc[3][lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 4 * q + r;
+                if (i >= job.gcols) continue;
+                int idx = -1;
+                if (jv)
+                    idx = job.off_w + i * job.xcols + cj;
+                else if (jb && job.off_b >= 0)
+                    idx = job.off_b + i;
+                if (idx < 0) continue;
+                buf.grads[idx] = g[r];
+                if (fuse)
+                    adam_update(ac, g[r], buf.params + idx, buf.exp_avg + idx,
+                                buf.exp_avg_sq + idx);
+            }
+        }
+        return;
+    }
+    const int lb = b - w.total_tiles;
+    if (lb < w.lvo_blocks) {
+        const int tiles = cdiv(a.st.n, kRows);
+        const int stride = partials_stride(a.mdl);
+        // d loss / d decoders.<m>.logvar: sum of the row tiles' partials
+        int m = 0;
+        while (lb >= w.lvo_block_begin[m + 1]) ++m;
+        const int col = (lb - w.lvo_block_begin[m]) * 256 + tid;
+        if (col < a.mdl.input_dim[m]) {
+            float g = 0.f;
+            const float* p = buf.partials + lvo_part_off(a.mdl, m) + col;
+            for (int t = 0; t < tiles; ++t) g += p[(size_t)t * stride];
+            const int idx = a.mdl.off_lvo[m] + col;
+            if (a.mdl.learn_output_scale) {
+                buf.grads[idx] = g;
+                if (fuse)
+                    adam_update(ac, g, buf.params + idx, buf.exp_avg + idx,
+                                buf.exp_avg_sq + idx);
+            } else {
+                buf.grads[idx] = 0.f;
+            }
+        }
+        return;
+    }
+    // last block: scalars of the step (run_epochs.py:89-128) + step counter
+    finalize_stats(a, tid);
+    if (tid == 0 && a.st.backward) buf.counters[1] += 1;
+}
+
+// forward-only finalisation of the scalars
+__global__ __launch_bounds__(256) void k_finalize(const KArgs a) {
+    finalize_stats(a, threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// k_adam: torch.optim.Adam on the flat buffer (used when the gradients pass
+// through an all-reduce first).  grid.y = segment, grid-stride over floats.
+// ---------------------------------------------------------------------------
+struct AdamSegs {
+    int32_t nseg;
+    int32_t begin[2 * MOPOE_MAX_MODS];
+    int32_t end[2 * MOPOE_MAX_MODS];
+    float grad_scale;
+    mopoe_adam adam;
+};
+
+__global__ __launch_bounds__(256) void k_adam(const mopoe_buffers buf, const AdamSegs s) {
+    const AdamCoef ac = adam_coef(s.adam, buf.counters[0]);
+    const int beg = s.begin[blockIdx.y], end = s.end[blockIdx.y];
+    for (int i = beg + blockIdx.x * blockDim.x + threadIdx.x; i < end;
+         i += gridDim.x * blockDim.x) {
+        const float g = buf.grads[i] * s.grad_scale;
+        adam_update(ac, g, buf.params + i, buf.exp_avg + i, buf.exp_avg_sq + i);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// free functions
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_poe(const float* __restrict__ mu,
+                                             const float* __restrict__ lv, int E,
+                                             long long numel, float eps,
+                                             float* __restrict__ omu,
+                                             float* __restrict__ olv) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numel;
+         i += (long long)gridDim.x * blockDim.x) {
+        float musum = 0.f, tsum = 0.f;
+        for (int e = 0; e < E; ++e) {
+            const float T = 1.f / (expf(lv[e * numel + i]) + eps);
+            musum += mu[e * numel + i] * T;
+            tsum += T;
+        }
+        omu[i] = musum / tsum;
+        olv[i] = logf(1.f / tsum);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_kl_partial(const float* __restrict__ mu,
+                                                    const float* __restrict__ lv,
+                                                    long long numel,
+                                                    float* __restrict__ scratch) {
+    __shared__ float wsum[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numel;
+         i += (long long)gridDim.x * blockDim.x)
+        s += 1.f - expf(lv[i]) - mu[i] * mu[i] + lv[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) scratch[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(64) void k_kl_final(const float* __restrict__ scratch,
+                                                 int nblocks, float norm,
+                                                 float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 64) s += scratch[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        float k = -0.5f * s;
+        if (norm > 0.f) k = k / norm;
+        *out = k;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reparam(const float* __restrict__ mu,
+                                                 const float* __restrict__ lv,
+                                                 const float* __restrict__ eps,
+                                                 long long numel, uint64_t seed,
+                                                 uint32_t stream_id,
+                                                 float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numel;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float e = eps ? eps[i] : philox_normal(seed, 0u, stream_id, (uint32_t)i);
+        out[i] = e * expf(0.5f * lv[i]) + mu[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mix_select(const float* __restrict__ mus,
+                                                    const float* __restrict__ lvs, int K,
+                                                    int n, int d,
+                                                    const int32_t* __restrict__ bounds,
+                                                    float* __restrict__ omu,
+                                                    float* __restrict__ olv) {
+    const long long total = (long long)n * d;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / d);
+        int k = 0;
+        while (k + 1 < K && row >= bounds[k + 1]) ++k;
+        omu[i] = mus[(size_t)k * total + i];
+        olv[i] = lvs[(size_t)k * total + i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* arg = "") {
+    snprintf(g_err, sizeof(g_err), fmt, arg);
+    return code;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return MOPOE_ERR_HIP;
+    }
+    return 0;
+}
+
+int validate(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* buf,
+             bool train) {
+    if (!mdl || !st || !buf) return fail(MOPOE_ERR_ARG, "null descriptor%s");
+    if (mdl->num_mods < 1 || mdl->num_mods > MOPOE_MAX_MODS)
+        return fail(MOPOE_ERR_ARG, "num_mods out of range%s");
+    if (mdl->class_dim < 1 || mdl->class_dim > 256)
+        return fail(MOPOE_ERR_ARG, "class_dim out of range%s");
+    if (st->n < 1) return fail(MOPOE_ERR_ARG, "empty batch%s");
+    if (st->present_mask <= 0 || st->present_mask >= (1 << mdl->num_mods))
+        return fail(MOPOE_ERR_ARG, "present_mask out of range%s");
+    if (st->num_subsets < 1 || st->num_subsets > MOPOE_MAX_SUBSETS)
+        return fail(MOPOE_ERR_ARG, "num_subsets out of range%s");
+    if (st->num_comp < 1 || st->num_comp > MOPOE_MAX_SUBSETS)
+        return fail(MOPOE_ERR_ARG, "num_comp out of range%s");
+    if (st->num_jobs < 1 || st->num_jobs > MOPOE_MAX_JOBS)
+        return fail(MOPOE_ERR_ARG, "num_jobs out of range%s");
+    for (int s = 0; s < st->num_subsets; ++s) {
+        if (st->sub_mask[s] == 0 || st->sub_mask[s] >= (1 << mdl->num_mods))
+            return fail(MOPOE_ERR_ARG, "subset mask out of range%s");
+        if (st->sub_avail[s] && (st->sub_mask[s] & ~st->present_mask))
+            return fail(MOPOE_ERR_ARG, "available subset has an absent member%s");
+        if (st->sub_kind[s] > MOPOE_SUB_SLICES)
+            return fail(MOPOE_ERR_ARG, "bad sub_kind%s");
+        for (int j = 0; j < MOPOE_MAX_MODS; ++j)
+            if (st->sub_members[s][j] >= mdl->num_mods)
+                return fail(MOPOE_ERR_ARG, "bad sub_members%s");
+    }
+    for (int k = 0; k < st->num_comp; ++k)
+        if (st->comp_sub[k] >= st->num_subsets || !st->sub_avail[st->comp_sub[k]])
+            return fail(MOPOE_ERR_ARG, "mixture component is not an available subset%s");
+    if (st->joint_mode == MOPOE_JOINT_EXPERT &&
+        (st->expert_subset < 0 || st->expert_subset >= st->num_subsets ||
+         !st->sub_avail[st->expert_subset]))
+        return fail(MOPOE_ERR_ARG, "use_expert subset unavailable%s");
+    if (st->joint_mode < 0 || st->joint_mode > MOPOE_JOINT_EXPERT)
+        return fail(MOPOE_ERR_ARG, "bad joint_mode%s");
+    if (train && st->joint_mode != MOPOE_JOINT_MIXTURE)
+        return fail(MOPOE_ERR_ARG, "training requires joint_mode mixture%s");
+    for (int j = 0; j < st->num_jobs; ++j) {
+        const int m = st->job_mod[j];
+        if (m >= mdl->num_mods || !((st->present_mask >> m) & 1))
+            return fail(MOPOE_ERR_ARG, "decoder job for an absent modality%s");
+        if (st->job_src[j] >= st->num_subsets ||
+            (st->job_src[j] >= 0 && !st->sub_avail[(int)st->job_src[j]]))
+            return fail(MOPOE_ERR_ARG, "decoder job source unavailable%s");
+        if (j > 0 && st->job_stream[j] < st->job_stream[j - 1])
+            return fail(MOPOE_ERR_ARG, "decoder jobs must be grouped by pass%s");
+    }
+    for (int m = 0; m < mdl->num_mods; ++m) {
+        if (mdl->input_dim[m] < 1 || mdl->style_dim[m] < 0)
+            return fail(MOPOE_ERR_ARG, "bad modality dims%s");
+        if (!((st->present_mask >> m) & 1)) continue;
+        if (!buf->x[m] || !buf->hidden[m] || !buf->heads[m] || !buf->z[m] || !buf->loc[m])
+            return fail(MOPOE_ERR_ARG, "null forward buffer%s");
+        if (train && (!buf->g_xhat[m] || !buf->g_heads[m] || !buf->g_pre[m]))
+            return fail(MOPOE_ERR_ARG, "null backward buffer%s");
+    }
+    if (!buf->params || !buf->subsets_mu || !buf->subsets_logvar || !buf->joint_mu ||
+        !buf->joint_logvar || !buf->stats || !buf->partials || !buf->counters)
+        return fail(MOPOE_ERR_ARG, "null shared buffer%s");
+    if (train && !buf->grads) return fail(MOPOE_ERR_ARG, "null grads%s");
+    if (reinterpret_cast<uintptr_t>(buf->params) & 255)
+        return fail(MOPOE_ERR_ARG, "params must be 256-byte aligned%s");
+    return 0;
+}
+
+int latent_lds_bytes(const mopoe_model& mdl, const mopoe_step& st) {
+    LatentLds L;
+    latent_lds_layout(mdl, st, kLatentWaves, L);
+    return L.total * (int)sizeof(float);
+}
+
+int launch_linear(const LinArgs& la, int max_k, int max_cols, hipStream_t s) {
+    const int kp = round_up(max_k < kEncKChunk ? max_k : kEncKChunk, 16);
+    const size_t lds = (size_t)kRows * (kp + 4) * sizeof(float);
+    hipLaunchKernelGGL(k_linear, dim3(cdiv(max_cols, 64), cdiv(la.n, kRows), la.ngroups),
+                       dim3(256), lds, s, la);
+    return check_launch("k_linear");
+}
+
+int launch_forward_part(const KArgs& ka, hipStream_t s) {
+    const mopoe_model& mdl = ka.mdl;
+    const int tiles = cdiv(ka.st.n, kRows);
+    LinArgs la;
+    memset(&la, 0, sizeof(la));
+    la.n = ka.st.n;
+    la.bump = ka.st.backward ? ka.buf.counters : nullptr;
+    int maxd = 1;
+    for (int m = 0; m < mdl.num_mods; ++m) {
+        if (!((ka.st.present_mask >> m) & 1)) continue;
+        const int d = mdl.input_dim[m];
+        maxd = d > maxd ? d : maxd;
+        LinGroup& g = la.g[la.ngroups++];
+        g.X = ka.buf.x[m];
+        g.rows = ka.buf.row_index;
+        g.W = ka.buf.params + mdl.off_w1[m];
+        g.b = ka.buf.params + mdl.off_b1[m];
+        g.Y = ka.buf.hidden[m];
+        g.K = d;
+        g.ldx = d;
+        g.ncols = kHid;
+        g.ldy = kHid;
+        g.relu = 1;
+    }
+    if (int rc = launch_linear(la, maxd, kHid, s)) return rc;
+
+    const int lds = ka.lds.total * (int)sizeof(float);
+    if (lds > 160 * 1024)
+        return fail(MOPOE_ERR_ARG, "model exceeds the 160 KiB LDS tile budget%s");
+    static thread_local int lds_opted = 0;
+    if (lds > 64 * 1024 && lds > lds_opted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_latent),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(MOPOE_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        lds_opted = lds;
+    }
+    hipLaunchKernelGGL(k_latent, dim3(tiles), dim3(kLatentThreads), (size_t)lds, s, ka);
+    return check_launch("k_latent");
+}
+
+void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w) {
+    const mopoe_model& mdl = ka.mdl;
+    const mopoe_step& st = ka.st;
+    memset(&w, 0, sizeof(w));
+    int tile = 0;
+    for (int m = 0; m < mdl.num_mods; ++m) {
+        if (!((st.present_mask >> m) & 1)) continue;
+        int njobs_m = 0;
+        for (int j = 0; j < st.num_jobs; ++j) njobs_m += st.job_mod[j] == m;
+        const int d = mdl.input_dim[m], nh = heads_dim(mdl, m), zd = z_dim(mdl, m);
+        WJob jobs[3] = {
+            {ka.buf.g_pre[m], ka.buf.x[m], ka.buf.row_index, kHid, kHid, d, d, st.n,
+             mdl.off_w1[m], mdl.off_b1[m], 0, 0},
+            {ka.buf.g_heads[m], ka.buf.hidden[m], nullptr, nh, nh, kHid, kHid, st.n,
+             mdl.off_wh[m], mdl.off_bh[m], 0, 0},
+            {ka.buf.g_xhat[m], ka.buf.z[m], nullptr, d, d, ldz_glb(mdl, m), zd,
+             njobs_m * st.n, mdl.off_wd[m], mdl.off_bd[m], 0, 0},
+        };
+        for (int k = 0; k < 3; ++k) {
+            WJob& jb = jobs[k];
+            jb.tiles_j = cdiv(jb.xcols + 1, 16);  // + bias column
+            jb.tile_begin = tile;
+            tile += cdiv(jb.gcols, 16) * jb.tiles_j;
+            w.jobs[w.njobs++] = jb;
+        }
+    }
+    w.total_tiles = tile;
+    int lb = 0;
+    for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
+        w.lvo_block_begin[m] = lb;
+        if (m < mdl.num_mods && ((st.present_mask >> m) & 1)) lb += cdiv(mdl.input_dim[m], 256);
+    }
+    w.lvo_block_begin[MOPOE_MAX_MODS] = lb;
+    w.lvo_blocks = lb;
+    w.fuse_adam = adam != nullptr;
+    if (adam) w.adam = *adam;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mopoe_abi_version(void) { return MOPOE_ABI_VERSION; }
+
+const char* mopoe_last_error(void) { return g_err; }
+
+int mopoe_model_layout(mopoe_model* mdl) {
+    if (!mdl) return fail(MOPOE_ERR_ARG, "null model%s");
+    if (mdl->num_mods < 1 || mdl->num_mods > MOPOE_MAX_MODS)
+        return fail(MOPOE_ERR_ARG, "num_mods out of range%s");
+    int off = 0;
+    auto seg = [&off](int count) {
+        const int o = off;
+        off += round_up(count, 64);
+        return o;
+    };
+    for (int m = 0; m < mdl->num_mods; ++m) {
+        const int d = mdl->input_dim[m], nh = heads_dim(*mdl, m), zd = z_dim(*mdl, m);
+        if (d < 1 || mdl->style_dim[m] < 0) return fail(MOPOE_ERR_ARG, "bad modality dims%s");
+        mdl->off_w1[m] = seg(kHid * d);
+        mdl->off_b1[m] = seg(kHid);
+        mdl->off_wh[m] = seg(nh * kHid);
+        mdl->off_bh[m] = seg(nh);
+        mdl->off_wd[m] = seg(d * zd);
+        mdl->off_bd[m] = seg(d);
+        mdl->off_lvo[m] = seg(d);
+    }
+    mdl->num_floats = off;
+    return 0;
+}
+
+int mopoe_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(mopoe_model);
+        case 1: return (int)sizeof(mopoe_step);
+        case 2: return (int)sizeof(mopoe_buffers);
+        case 3: return (int)sizeof(mopoe_adam);
+        case 4: return (int)offsetof(mopoe_step, job_eps_content);
+        case 5: return (int)offsetof(mopoe_step, comp_w);
+        case 6: return (int)offsetof(mopoe_buffers, partials);
+        case 7: return (int)offsetof(mopoe_model, num_floats);
+        default: return -1;
+    }
+}
+
+int mopoe_ldz(const mopoe_model* mdl, int mod) { return ldz_glb(*mdl, mod); }
+
+int mopoe_partials_stride(const mopoe_model* mdl) { return partials_stride(*mdl); }
+
+int mopoe_latent_lds_bytes(const mopoe_model* mdl, const mopoe_step* st) {
+    return latent_lds_bytes(*mdl, *st);
+}
+
+int mopoe_forward(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* buf,
+                  void* stream) {
+    if (int rc = validate(mdl, st, buf, false)) return rc;
+    KArgs ka;
+    ka.mdl = *mdl;
+    ka.st = *st;
+    ka.buf = *buf;
+    ka.st.backward = 0;
+    latent_lds_layout(ka.mdl, ka.st, kLatentWaves, ka.lds);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = launch_forward_part(ka, s)) return rc;
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, ka);
+    return check_launch("k_finalize");
+}
+
+int mopoe_train_step(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* buf,
+                     const mopoe_adam* adam, void* stream) {
+    if (int rc = validate(mdl, st, buf, true)) return rc;
+    if (adam && (!buf->exp_avg || !buf->exp_avg_sq))
+        return fail(MOPOE_ERR_ARG, "null Adam state%s");
+    KArgs ka;
+    ka.mdl = *mdl;
+    ka.st = *st;
+    ka.buf = *buf;
+    ka.st.backward = 1;
+    ka.st.sample = 1;
+    latent_lds_layout(ka.mdl, ka.st, kLatentWaves, ka.lds);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = launch_forward_part(ka, s)) return rc;
+    WArgs w;
+    build_wargs(ka, adam, w);
+    hipLaunchKernelGGL(k_wgrad, dim3(w.total_tiles + w.lvo_blocks + 1), dim3(256), 0, s, ka, w);
+    return check_launch("k_wgrad");
+}
+
+int mopoe_adam_step(const mopoe_model* mdl, int32_t present_mask, const mopoe_buffers* buf,
+                    const mopoe_adam* adam, float grad_scale, void* stream) {
+    if (!mdl || !buf || !adam) return fail(MOPOE_ERR_ARG, "null descriptor%s");
+    if (!buf->params || !buf->grads || !buf->exp_avg || !buf->exp_avg_sq || !buf->counters)
+        return fail(MOPOE_ERR_ARG, "null optimiser buffer%s");
+    AdamSegs sg;
+    memset(&sg, 0, sizeof(sg));
+    for (int m = 0; m < mdl->num_mods; ++m) {
+        if (!((present_mask >> m) & 1)) continue;
+        sg.begin[sg.nseg] = mdl->off_w1[m];
+        sg.end[sg.nseg++] = mdl->off_bh[m] + heads_dim(*mdl, m);
+        sg.begin[sg.nseg] = mdl->off_wd[m];
+        sg.end[sg.nseg++] = mdl->learn_output_scale ? mdl->off_lvo[m] + mdl->input_dim[m]
+                                                    : mdl->off_bd[m] + mdl->input_dim[m];
+    }
+    if (sg.nseg == 0) return fail(MOPOE_ERR_ARG, "empty present_mask%s");
+    sg.grad_scale = grad_scale;
+    sg.adam = *adam;
+    hipLaunchKernelGGL(k_adam, dim3(128, sg.nseg), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *buf, sg);
+    return check_launch("k_adam");
+}
+
+int mopoe_linear(const float* x, int32_t n, int32_t k, const float* w, const float* b,
+                 int32_t ncols, int32_t relu, float* y, void* stream) {
+    if (!x || !w || !y || n < 1 || k < 1 || ncols < 1)
+        return fail(MOPOE_ERR_ARG, "mopoe_linear: bad argument%s");
+    LinArgs la;
+    memset(&la, 0, sizeof(la));
+    la.n = n;
+    la.ngroups = 1;
+    LinGroup& g = la.g[0];
+    g.X = x;
+    g.W = w;
+    g.b = b;
+    g.Y = y;
+    g.K = k;
+    g.ldx = k;
+    g.ncols = ncols;
+    g.ldy = ncols;
+    g.relu = relu;
+    return launch_linear(la, k, ncols, static_cast<hipStream_t>(stream));
+}
+
+int mopoe_poe(const float* mu, const float* logvar, int32_t num_experts, int64_t numel,
+              float eps, float* out_mu, float* out_logvar, void* stream) {
+    if (!mu || !logvar || !out_mu || !out_logvar || num_experts < 1 || numel < 1)
+        return fail(MOPOE_ERR_ARG, "mopoe_poe: bad argument%s");
+    const int blocks = (int)((numel + 255) / 256 < 2048 ? (numel + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_poe, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), mu,
+                       logvar, num_experts, (long long)numel, eps, out_mu, out_logvar);
+    return check_launch("k_poe");
+}
+
+int mopoe_kl_divergence(const float* mu, const float* logvar, int64_t numel, float norm_value,
+                        float* scratch, float* out, void* stream) {
+    if (!mu || !logvar || !scratch || !out || numel < 1)
+        return fail(MOPOE_ERR_ARG, "mopoe_kl_divergence: bad argument%s");
+    const int blocks = (int)((numel + 255) / 256 < 1024 ? (numel + 255) / 256 : 1024);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_kl_partial, dim3(blocks), dim3(256), 0, s, mu, logvar,
+                       (long long)numel, scratch);
+    if (int rc = check_launch("k_kl_partial")) return rc;
+    hipLaunchKernelGGL(k_kl_final, dim3(1), dim3(64), 0, s, scratch, blocks, norm_value, out);
+    return check_launch("k_kl_final");
+}
+
+int mopoe_reparameterize(const float* mu, const float* logvar, const float* eps, int64_t numel,
+                         uint64_t seed, uint64_t stream_id, float* out, void* stream) {
+    if (!mu || !logvar || !out || numel < 1)
+        return fail(MOPOE_ERR_ARG, "mopoe_reparameterize: bad argument%s");
+    const int blocks = (int)((numel + 255) / 256 < 2048 ? (numel + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_reparam, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       mu, logvar, eps, (long long)numel, seed, (uint32_t)stream_id, out);
+    return check_launch("k_reparam");
+}
+
+int mopoe_mixture_select(const float* mus, const float* logvars, int32_t num_comp, int32_t n,
+                         int32_t d, const int32_t* bounds, float* out_mu, float* out_logvar,
+                         void* stream) {
+    if (!mus || !logvars || !bounds || !out_mu || !out_logvar || num_comp < 1 || n < 1 || d < 1)
+        return fail(MOPOE_ERR_ARG, "mopoe_mixture_select: bad argument%s");
+    const long long total = (long long)n * d;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_mix_select, dim3(blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), mus, logvars, num_comp, n, d, bounds,
+                       out_mu, out_logvar);
+    return check_launch("k_mix_select");
+}
+
+}  // extern "C"

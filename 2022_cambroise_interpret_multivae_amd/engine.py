@@ -1,0 +1,298 @@
+"""MoPoEEngine: owns the device buffers of one model and drives the C ABI.
+
+This is the host side of the hot path: flat parameter / gradient / Adam-state
+buffers (one contiguous float32 allocation each, so the data-parallel
+all-reduce is a single collective), per-batch-size workspaces, and the three
+calls `forward`, `train_step`, `adam_step`.  All compute happens in
+libmopoe_hip.so; there is no PyTorch fallback.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import _lib as L
+from .plan import ModelSpec
+
+
+class Workspace:
+    """Caller-owned buffers of one (batch size, jobs-per-modality) shape."""
+
+    def __init__(self, spec, n, slots, device, backward):
+        f = dict(dtype=torch.float32, device=device)
+        M, D, S = spec.num_mods, spec.class_dim, len(spec.subset_keys)
+        self.n = n
+        self.slots = slots
+        self.hidden = [torch.empty(n, L.HIDDEN, **f) for _ in range(M)]
+        self.heads = [torch.empty(n, spec.heads_dim(m), **f) for m in range(M)]
+        self.subsets_mu = torch.empty(S, n, D, **f)
+        self.subsets_logvar = torch.empty(S, n, D, **f)
+        self.joint_mu = torch.empty(n, D, **f)
+        self.joint_logvar = torch.empty(n, D, **f)
+        self.z = [torch.zeros(slots * n, spec.ldz(m), **f) for m in range(M)]
+        self.loc = [torch.empty(slots * n, spec.input_dim[m], **f)
+                    for m in range(M)]
+        self.stats = torch.zeros(L.NUM_STATS, **f)
+        tiles = (n + L.ROWS - 1) // L.ROWS
+        stride = L.lib.mopoe_partials_stride(spec.c_model)
+        self.partials = torch.zeros(tiles, stride, **f)
+        self.backward = backward
+        if backward:
+            self.g_xhat = [torch.empty(slots * n, spec.input_dim[m], **f)
+                           for m in range(M)]
+            self.g_heads = [torch.empty(n, spec.heads_dim(m), **f)
+                            for m in range(M)]
+            self.g_pre = [torch.empty(n, L.HIDDEN, **f) for m in range(M)]
+
+
+class MoPoEEngine:
+    def __init__(self, spec, device="cuda", seed=None):
+        if not isinstance(spec, ModelSpec):
+            raise TypeError("spec must be a ModelSpec")
+        self.spec = spec
+        self.device = torch.device(device)
+        P = spec.num_floats
+        self._on_gpu = self.device.type == "cuda"
+        f = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(P, **f)
+        self.grads = torch.zeros(P, **f)
+        self.exp_avg = torch.zeros(P, **f)
+        self.exp_avg_sq = torch.zeros(P, **f)
+        self.counters = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.views = spec.param_views(self.params)
+        self.grad_views = spec.param_views(self.grads)
+        self.seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1)
+        self._calls = 0
+        self._ws = {}
+        self._keep = None   # tensors the in-flight kernels read (x, eps)
+        self.adam = L.Adam(spec.lr, spec.betas[0], spec.betas[1], spec.adam_eps)
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------ params
+    def reset_parameters(self, generator=None):
+        """nn.Linear's default init law (kaiming_uniform(a=sqrt(5)) = U(-1/sqrt
+        (fan_in), 1/sqrt(fan_in)) for weight and bias) and decoder logvar =
+        initial_out_logvar (networks.py:58-62)."""
+        with torch.no_grad():
+            for name, v in self.views.items():
+                if name.endswith(".logvar"):
+                    v.fill_(self.spec.initial_out_logvar)
+                    continue
+                wname = name if name.endswith(".weight") else name[:-4] + "weight"
+                bound = 1.0 / (self.views[wname].shape[1] ** 0.5)
+                v.copy_((torch.rand(v.shape, generator=generator) * 2 - 1) * bound)
+
+    def load_params(self, named):
+        with torch.no_grad():
+            for name, v in self.views.items():
+                v.copy_(named[name].reshape(v.shape))
+
+    def named_params(self):
+        return OrderedDict((k, v.detach().clone()) for k, v in self.views.items())
+
+    def step_count(self):
+        return int(self.counters[0].item())
+
+    # --------------------------------------------------------------- buffers
+    def workspace(self, n, slots, backward, fresh=False):
+        if fresh:
+            return Workspace(self.spec, n, slots, self.device, backward)
+        key = (n, slots, backward)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = Workspace(self.spec, n, slots, self.device, backward)
+            self._ws[key] = ws
+        return ws
+
+    def _buffers(self, ws, x, row_index):
+        b = L.Buffers()
+        b.params = L.ptr(self.params)
+        b.grads = L.ptr(self.grads)
+        b.exp_avg = L.ptr(self.exp_avg)
+        b.exp_avg_sq = L.ptr(self.exp_avg_sq)
+        b.counters = L.ptr(self.counters)
+        b.row_index = L.ptr(row_index)
+        for m, name in enumerate(self.spec.names):
+            if name in x:
+                b.x[m] = L.ptr(x[name])
+            b.hidden[m] = L.ptr(ws.hidden[m])
+            b.heads[m] = L.ptr(ws.heads[m])
+            b.z[m] = L.ptr(ws.z[m])
+            b.loc[m] = L.ptr(ws.loc[m])
+            if ws.backward:
+                b.g_xhat[m] = L.ptr(ws.g_xhat[m])
+                b.g_heads[m] = L.ptr(ws.g_heads[m])
+                b.g_pre[m] = L.ptr(ws.g_pre[m])
+        b.subsets_mu = L.ptr(ws.subsets_mu)
+        b.subsets_logvar = L.ptr(ws.subsets_logvar)
+        b.joint_mu = L.ptr(ws.joint_mu)
+        b.joint_logvar = L.ptr(ws.joint_logvar)
+        b.stats = L.ptr(ws.stats)
+        b.partials = L.ptr(ws.partials)
+        return b
+
+    def _prepare(self, batch, row_index):
+        L.require_gpu()
+        if not self._on_gpu:
+            raise L.MopoeError("engine was created on %s" % self.device)
+        x = OrderedDict()
+        n = None
+        for name, v in batch.items():
+            # run_epochs.py:85-86: .to(device).float()
+            t = v.to(self.device, dtype=torch.float32).contiguous()
+            m = self.spec.names.index(name)
+            if t.dim() != 2 or t.shape[1] != self.spec.input_dim[m]:
+                raise ValueError("batch[%r] has shape %s, expected (N, %d)" % (
+                    name, tuple(t.shape), self.spec.input_dim[m]))
+            x[name] = t
+            rows = t.shape[0] if row_index is None else row_index.shape[0]
+            if n is not None and rows != n:
+                raise ValueError("modalities disagree on the batch size")
+            n = rows
+        if row_index is not None:
+            row_index = row_index.to(self.device, dtype=torch.int32).contiguous()
+        return x, n, row_index
+
+    def _bind_noise(self, plan, step, eps):
+        """Point the step at injected eps tensors (reference draw order)."""
+        keep = []
+        for j in range(L.MAX_JOBS):
+            step.job_eps_content[j] = None
+            step.job_eps_style[j] = None
+        if eps is None:
+            return keep
+        if len(eps) != len(plan.noise_slots):
+            raise ValueError("expected %d eps tensors, got %d" % (
+                len(plan.noise_slots), len(eps)))
+        for (kind, j), e in zip(plan.noise_slots, eps):
+            t = e.to(self.device, dtype=torch.float32).contiguous()
+            m = plan.jobs[j][0]
+            want = (plan.n, self.spec.class_dim if kind == "content"
+                    else self.spec.style_dim[m])
+            if tuple(t.shape) != want:
+                raise ValueError("eps shape %s, expected %s" % (tuple(t.shape), want))
+            keep.append(t)
+            if kind == "content":
+                for jj, jb in enumerate(plan.jobs):
+                    if jb[3] == plan.jobs[j][3]:
+                        step.job_eps_content[jj] = t.data_ptr()
+            else:
+                step.job_eps_style[j] = t.data_ptr()
+        return keep
+
+    # ----------------------------------------------------------------- calls
+    def forward(self, batch, sample=True, use_expert=None, eps=None,
+                row_index=None, loss=False, fresh=True):
+        """mopoe_forward: encoder, fusion, latent, decoder, loss scalars."""
+        x, n, row_index = self._prepare(batch, row_index)
+        plan = self.spec.plan(list(x.keys()), n, sample, use_expert, False, loss)
+        slots = max(plan.jobs_per_mod)
+        ws = self.workspace(n, slots, False, fresh=fresh)
+        step = plan.c_step
+        keep = self._bind_noise(plan, step, eps)
+        self._calls += 1
+        step.seed = (self.seed + 0x9E3779B97F4A7C15 * self._calls) & (2 ** 64 - 1)
+        buf = self._buffers(ws, x, row_index)
+        L.check(L.lib.mopoe_forward(self.spec.c_model, step, buf, L.stream_ptr()),
+                "mopoe_forward")
+        self._keep = (x, keep, row_index)
+        return plan, ws
+
+    def train_step(self, batch, eps=None, row_index=None, apply_adam=True):
+        """mopoe_train_step: forward + backward (+ fused Adam)."""
+        x, n, row_index = self._prepare(batch, row_index)
+        plan = self.spec.plan(list(x.keys()), n, True, None, True, True)
+        slots = max(plan.jobs_per_mod)
+        ws = self.workspace(n, slots, True)
+        step = plan.c_step
+        keep = self._bind_noise(plan, step, eps)
+        step.seed = self.seed
+        buf = self._buffers(ws, x, row_index)
+        adam = C.byref(self.adam) if apply_adam else None
+        L.check(L.lib.mopoe_train_step(self.spec.c_model, step, buf, adam,
+                                       L.stream_ptr()), "mopoe_train_step")
+        self._keep = (x, keep, row_index)
+        self.last_present_mask = step.present_mask
+        return plan, ws
+
+    def adam_step(self, present_mask=None, grad_scale=1.0):
+        """mopoe_adam_step on the flat buffers (after a gradient all-reduce)."""
+        L.require_gpu()
+        if present_mask is None:
+            present_mask = self.last_present_mask
+        b = L.Buffers()
+        b.params = L.ptr(self.params)
+        b.grads = L.ptr(self.grads)
+        b.exp_avg = L.ptr(self.exp_avg)
+        b.exp_avg_sq = L.ptr(self.exp_avg_sq)
+        b.counters = L.ptr(self.counters)
+        L.check(L.lib.mopoe_adam_step(self.spec.c_model, present_mask, b,
+                                      C.byref(self.adam), grad_scale,
+                                      L.stream_ptr()), "mopoe_adam_step")
+
+    # --------------------------------------------------------------- results
+    def results(self, plan, ws):
+        """The dict BaseMMVae.forward returns (BaseMMVae.py:137-165), built
+        from views of the workspace (no copies)."""
+        spec = self.spec
+        n, D = plan.n, spec.class_dim
+        enc_mods = OrderedDict()
+        for m, name in enumerate(spec.names):
+            s = spec.style_dim[m]
+            if name in plan.present:
+                h = ws.heads[m]
+                enc_mods[name + "_style"] = [h[:, 0:s], h[:, s:2 * s]] \
+                    if spec.has_style(m) else [None, None]
+                enc_mods[name] = [h[:, 2 * s:2 * s + D], h[:, 2 * s + D:2 * s + 2 * D]]
+            else:
+                enc_mods[name + "_style"] = [None, None]
+                enc_mods[name] = [None, None]
+        subsets = OrderedDict()
+        for key, s in zip(plan.avail_keys, plan.avail_idx):
+            subsets[key] = [ws.subsets_mu[s], ws.subsets_logvar[s]]
+        ci = plan.comp_idx
+        if ci == list(range(ci[0], ci[0] + len(ci))):
+            mus = ws.subsets_mu[ci[0]:ci[0] + len(ci)]
+            logvars = ws.subsets_logvar[ci[0]:ci[0] + len(ci)]
+        else:
+            idx = torch.tensor(ci, device=self.device)
+            mus = ws.subsets_mu.index_select(0, idx)
+            logvars = ws.subsets_logvar.index_select(0, idx)
+        latents = {
+            "modalities": enc_mods, "mus": mus, "logvars": logvars,
+            "weights": torch.tensor(plan.comp_w, dtype=torch.float32,
+                                    device=self.device),
+            "joint": [ws.joint_mu, ws.joint_logvar], "subsets": subsets}
+        res = {"latents": latents, "group_distr": latents["joint"]}
+        res["joint_divergence"] = ws.stats[L.STAT_JOINT_DIV]
+        if ci == list(range(ci[0], ci[0] + len(ci))):
+            res["individual_divs"] = ws.stats[L.STAT_KLD_SUBSET + ci[0]:
+                                              L.STAT_KLD_SUBSET + ci[0] + len(ci)]
+        else:
+            res["individual_divs"] = ws.stats[L.STAT_KLD_SUBSET:].index_select(
+                0, torch.tensor(ci, device=self.device))
+        res["dyn_prior"] = None
+        rec = OrderedDict()
+        for m, name in enumerate(spec.names):
+            if name in plan.present:
+                scale = (self.views["decoders.%s.logvar" % name] * 0.5).exp()
+                rec[name] = torch.distributions.Normal(
+                    ws.loc[m][:n], scale, validate_args=False)
+        res["rec"] = rec
+        return res
+
+    def scalars(self, plan, ws):
+        """log_probs / klds / total_loss of run_epochs.basic_routine_epoch
+        (run_epochs.py:89-135) as 0-dim views of the stats buffer."""
+        spec = self.spec
+        log_probs, klds, klds_style = OrderedDict(), OrderedDict(), OrderedDict()
+        for j, (m, slot, src, pas) in enumerate(plan.jobs):
+            if pas == 0:
+                log_probs[spec.names[m]] = ws.stats[L.STAT_NLL + j]
+        for key, s in zip(plan.avail_keys, plan.avail_idx):
+            klds[key] = ws.stats[L.STAT_KLD_SUBSET + s]
+        for m in plan.present_idx:
+            if spec.has_style(m):
+                klds_style[spec.names[m] + "_style"] = ws.stats[L.STAT_KLD_STYLE + m]
+        return {"log_probs": log_probs, "klds": klds, "klds_style": klds_style,
+                "total_loss": ws.stats[L.STAT_TOTAL_LOSS]}

@@ -1,0 +1,310 @@
+"""Host logic of the hot path: turns the reference's flags + the composition of
+a batch into the `mopoe_model` / `mopoe_step` descriptors of the C ABI.
+
+Everything the reference decides in Python per batch is decided here, once per
+(present modalities, N, mode) and cached:
+  * the ordered powerset of modalities          (utils/BaseExperiment.py:58-79)
+  * which subsets are available / fused how      (utils/BaseMMVae.py:109-134,190-216)
+  * the mixture components, their weights and slice sizes
+                                                 (utils/BaseMMVae.py:225-227, utils/utils.py:58-85)
+  * the loss coefficients of every KL / NLL term (run_epochs.py:98-128, utils/utils.py:88-112)
+Paths are relative to the reference's experiments/ directory.
+"""
+from collections import OrderedDict
+from itertools import chain, combinations
+
+import torch
+
+from . import _lib as L
+
+METHODS = ("joint_elbo", "poe", "moe")
+
+
+class ModelSpec:
+    """Static description of a model: the flags the hot path reads
+    (workflow.py:98-145).  Accepts the reference's flags object via
+    ModelSpec.from_flags."""
+
+    def __init__(self, names, input_dim, style_dim, class_dim=20,
+                 method="joint_elbo", factorized=True, beta=1.0,
+                 beta_style=1.0, beta_content=1.0, initial_out_logvar=-3.0,
+                 learn_output_scale=True, lr=0.002, betas=(0.9, 0.999),
+                 adam_eps=1e-8, rec_weights=None):
+        if method not in METHODS:
+            raise NotImplementedError(
+                "method %r: only joint_elbo / poe / moe are on the MI355X hot "
+                "path (SURVEY.md section 8a)" % (method,))
+        self.names = list(names)
+        M = len(self.names)
+        if not 1 <= M <= L.MAX_MODS:
+            raise ValueError("1..%d modalities supported" % L.MAX_MODS)
+        self.input_dim = [int(d) for d in input_dim]
+        # multimodal_cohort/experiment.py:133-136
+        if isinstance(style_dim, int):
+            style_dim = [style_dim] * M
+        elif len(style_dim) != M:
+            style_dim = [style_dim[0]] * M
+        # workflow.py:148-149
+        self.style_dim = [int(s) for s in style_dim] if factorized else [0] * M
+        self.class_dim = int(class_dim)
+        self.method = method
+        self.factorized = bool(factorized)
+        self.beta = float(beta)
+        self.beta_style = float(beta_style)
+        self.beta_content = float(beta_content)
+        self.initial_out_logvar = float(initial_out_logvar)
+        self.learn_output_scale = bool(learn_output_scale)
+        self.lr = float(lr)
+        self.betas = (float(betas[0]), float(betas[1]))
+        self.adam_eps = float(adam_eps)
+        self.rec_weights = dict(rec_weights) if rec_weights else \
+            {n: 1.0 for n in self.names}
+
+        # BaseExperiment.set_subsets: key -> member names (sorted)
+        self.subsets = OrderedDict()
+        for mod_names in chain.from_iterable(
+                combinations(self.names, n) for n in range(1, M + 1)):
+            self.subsets["_".join(sorted(mod_names))] = sorted(mod_names)
+        self.subset_keys = list(self.subsets.keys())
+
+        c = L.Model()
+        c.num_mods = M
+        c.class_dim = self.class_dim
+        for m in range(M):
+            c.input_dim[m] = self.input_dim[m]
+            c.style_dim[m] = self.style_dim[m]
+        c.learn_output_scale = int(self.learn_output_scale)
+        L.check(L.lib.mopoe_model_layout(c), "mopoe_model_layout")
+        self.c_model = c
+        self.num_floats = c.num_floats
+        self._plans = {}
+
+    @classmethod
+    def from_flags(cls, flags, names):
+        """Build from the SimpleNamespace workflow.train_exp assembles."""
+        if getattr(flags, "modality_jsd", False):
+            raise NotImplementedError("method jsd is outside the hot path")
+        if getattr(flags, "num_hidden_layer_encoder", 1) != 1 or \
+                getattr(flags, "num_hidden_layer_decoder", 0) != 0:
+            raise NotImplementedError(
+                "the HIP path implements the train_exp default topology: one "
+                "hidden encoder layer, no hidden decoder layer")
+        if getattr(flags, "learn_output_sample_scale", False):
+            raise NotImplementedError("learn_output_sample_scale")
+        if getattr(flags, "likelihood", "normal") != "normal":
+            raise NotImplementedError("only the normal likelihood is fused")
+        if getattr(flags, "dropout_rate", 0.0) != 0.0:
+            raise NotImplementedError("dropout_rate != 0")
+        method = ("poe" if flags.modality_poe else
+                  "moe" if flags.modality_moe else "joint_elbo")
+        return cls(names, flags.input_dim, flags.style_dim,
+                   class_dim=flags.class_dim, method=method,
+                   factorized=flags.factorized_representation,
+                   beta=flags.beta, beta_style=flags.beta_style,
+                   beta_content=flags.beta_content,
+                   initial_out_logvar=flags.initial_out_logvar,
+                   learn_output_scale=flags.learn_output_scale,
+                   lr=getattr(flags, "initial_learning_rate", 0.002),
+                   betas=(getattr(flags, "beta_1", 0.9),
+                          getattr(flags, "beta_2", 0.999)))
+
+    @property
+    def num_mods(self):
+        return len(self.names)
+
+    def has_style(self, m):
+        return self.factorized and self.style_dim[m] > 0
+
+    def heads_dim(self, m):
+        return 2 * self.style_dim[m] + 2 * self.class_dim
+
+    def z_dim(self, m):
+        return self.style_dim[m] + self.class_dim
+
+    def ldz(self, m):
+        return (self.z_dim(m) + 3) // 4 * 4
+
+    # ------------------------------------------------------------------
+    def param_views(self, flat):
+        """name (reference state_dict key) -> view into the flat buffer."""
+        c = self.c_model
+        D, H = self.class_dim, L.HIDDEN
+        out = OrderedDict()
+        for m, name in enumerate(self.names):
+            d, s = self.input_dim[m], self.style_dim[m]
+            e = "encoders.%s." % name
+            out[e + "shared_encoder.0.weight"] = \
+                flat[c.off_w1[m]:c.off_w1[m] + H * d].view(H, d)
+            out[e + "shared_encoder.0.bias"] = flat[c.off_b1[m]:c.off_b1[m] + H]
+            wh, bh = c.off_wh[m], c.off_bh[m]
+
+            def rows(r0, n):
+                return flat[wh + r0 * H:wh + (r0 + n) * H].view(n, H)
+
+            out[e + "class_mu.weight"] = rows(2 * s, D)
+            out[e + "class_mu.bias"] = flat[bh + 2 * s:bh + 2 * s + D]
+            out[e + "class_logvar.weight"] = rows(2 * s + D, D)
+            out[e + "class_logvar.bias"] = flat[bh + 2 * s + D:bh + 2 * s + 2 * D]
+            if self.has_style(m):
+                out[e + "style_mu.weight"] = rows(0, s)
+                out[e + "style_mu.bias"] = flat[bh:bh + s]
+                out[e + "style_logvar.weight"] = rows(s, s)
+                out[e + "style_logvar.bias"] = flat[bh + s:bh + 2 * s]
+        for m, name in enumerate(self.names):
+            d, zd = self.input_dim[m], self.z_dim(m)
+            k = "decoders.%s." % name
+            out[k + "logvar"] = flat[c.off_lvo[m]:c.off_lvo[m] + d].view(1, d)
+            out[k + "out_mu.weight"] = \
+                flat[c.off_wd[m]:c.off_wd[m] + d * zd].view(d, zd)
+            out[k + "out_mu.bias"] = flat[c.off_bd[m]:c.off_bd[m] + d]
+        return out
+
+    # ------------------------------------------------------------------
+    def plan(self, present, n, sample=True, use_expert=None, backward=False,
+             loss=False):
+        """`loss`: also run the decoder passes that only the loss needs (the
+        unimodal forwards of method poe, run_epochs.py:104-128)."""
+        key = (tuple(present), int(n), bool(sample), use_expert, bool(backward),
+               bool(loss or backward))
+        p = self._plans.get(key)
+        if p is None:
+            p = StepPlan(self, *key)
+            self._plans[key] = p
+        return p
+
+
+def _uniform_slice(n, k):
+    """int(floor(N * w_0)) in the reference's float32 tensor arithmetic, with
+    w = reweight_weights((1/float(K)) * ones(K))  (BaseMMVae.py:207,225;
+    utils/utils.py:58-60,79)."""
+    w = (1 / float(k)) * torch.ones(k)
+    w = w / w.sum()
+    return int(torch.floor(n * w[0])), [float(v) for v in w]
+
+
+class StepPlan:
+    """One `mopoe_step` descriptor + the bookkeeping to read results back."""
+
+    def __init__(self, spec, present, n, sample, use_expert, backward, loss):
+        self.spec = spec
+        self.n = n
+        self.sample = sample
+        self.backward = backward
+        names = spec.names
+        for name in present:
+            if name not in names:
+                raise KeyError("unknown modality %r" % (name,))
+        if not present:
+            raise ValueError("empty batch")
+        self.present = list(present)          # batch key order
+        self.present_idx = [m for m, nm in enumerate(names) if nm in present]
+        mask = sum(1 << m for m in self.present_idx)
+        M = spec.num_mods
+        st = L.Step()
+        st.n = n
+        st.present_mask = mask
+        st.sample = int(sample)
+        st.backward = int(backward)
+        st.num_subsets = len(spec.subset_keys)
+
+        # subsets (BaseMMVae.inference :190-216)
+        self.avail_keys = []
+        avail_idx = []
+        for s, (key, members) in enumerate(spec.subsets.items()):
+            smask = sum(1 << names.index(nm) for nm in members)
+            st.sub_mask[s] = smask
+            ok = all(nm in present for nm in members)
+            st.sub_avail[s] = int(ok)
+            for j, nm in enumerate(members):
+                st.sub_members[s][j] = names.index(nm)
+            E = len(members)
+            if spec.method == "moe":
+                st.sub_kind[s] = L.SUB_SLICES
+                st.sub_f[s] = _uniform_slice(n, E)[0]
+            elif spec.method == "poe" or E == M:   # BaseMMVae.poe_fusion :110-111
+                st.sub_kind[s] = L.SUB_POE_PRIOR
+            else:
+                st.sub_kind[s] = L.SUB_POE
+            if ok:
+                self.avail_keys.append(key)
+                avail_idx.append(s)
+        self.avail_idx = avail_idx
+
+        # mixture components (fusion_condition_* :125-134)
+        if spec.method == "moe":
+            comp = [s for s in avail_idx if len(spec.subsets[spec.subset_keys[s]]) == 1]
+        elif spec.method == "poe":
+            comp = [s for s in avail_idx
+                    if len(spec.subsets[spec.subset_keys[s]]) == len(present)]
+        else:
+            comp = list(avail_idx)
+        K = len(comp)
+        f, w = _uniform_slice(n, K)
+        st.num_comp = K
+        st.comp_f = f
+        for k, s in enumerate(comp):
+            st.comp_sub[k] = s
+            st.comp_w[k] = w[k]
+        self.comp_idx = comp
+        self.comp_w = w
+
+        if use_expert is not None:
+            if use_expert not in self.avail_keys:
+                raise KeyError(use_expert)     # as distr_subsets[use_expert] would
+            st.joint_mode = L.JOINT_EXPERT
+            st.expert_subset = spec.subset_keys.index(use_expert)
+        else:
+            st.joint_mode = L.JOINT_MIXTURE if sample else L.JOINT_MEAN
+
+        # decoder jobs + the order in which the reference draws eps
+        jobs = []          # (modality index, slot, src subset or -1, pass)
+        for m in self.present_idx:
+            jobs.append((m, 0, -1, 0))
+        if spec.method == "poe" and loss:
+            for p, nm in enumerate(self.present):     # run_epochs.py:107 order
+                m = names.index(nm)
+                jobs.append((m, 1, spec.subset_keys.index(nm), 1 + p))
+        if len(jobs) > L.MAX_JOBS:
+            raise ValueError("too many decoder jobs")
+        st.num_jobs = len(jobs)
+        for j, (m, slot, src, pas) in enumerate(jobs):
+            st.job_mod[j] = m
+            st.job_slot[j] = slot
+            st.job_src[j] = src
+            st.job_stream[j] = pas
+            st.job_nll_coef[j] = spec.rec_weights[names[m]] if pas == 0 else 1.0
+        self.jobs = jobs
+        self.jobs_per_mod = [sum(1 for jb in jobs if jb[0] == m) for m in range(M)]
+        # noise tape order (BaseMMVae.forward :143,155-159, one group per call)
+        self.noise_slots = []
+        if sample:
+            passes = sorted(set(jb[3] for jb in jobs))
+            for pas in passes:
+                first = next(j for j, jb in enumerate(jobs) if jb[3] == pas)
+                self.noise_slots.append(("content", first))
+                for j, jb in enumerate(jobs):
+                    if jb[3] == pas and spec.has_style(jb[0]):
+                        self.noise_slots.append(("style", j))
+
+        # loss coefficients
+        b, bs, bc = spec.beta, spec.beta_style, spec.beta_content
+        if spec.method in ("joint_elbo", "moe"):     # run_epochs.py:95-103
+            for k, s in enumerate(comp):
+                st.sub_kl_coef[s] = b * bc * w[k]
+            for m in self.present_idx:
+                if spec.has_style(m):
+                    st.style_kl_coef[m] = b * bs * bs
+        else:                                        # run_epochs.py:104-128
+            coef = [0.0] * len(spec.subset_keys)
+            coef[comp[0]] += b * bc                  # elbo_joint: K = 1, w = 1
+            for nm in self.present:                  # unimodal elbos use klds[m]
+                coef[spec.subset_keys.index(nm)] += b * bc
+            for s, v in enumerate(coef):
+                st.sub_kl_coef[s] = v
+            for m in self.present_idx:
+                if spec.has_style(m):
+                    st.style_kl_coef[m] = 2.0 * b * bs * bs
+        self.c_step = st
+
+    def lds_bytes(self):
+        return L.lib.mopoe_latent_lds_bytes(self.spec.c_model, self.c_step)

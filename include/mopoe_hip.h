@@ -1,0 +1,253 @@
+/*
+ * mopoe_hip.h -- C ABI of libmopoe_hip.so: the MI355X (gfx950) MoPoE-VAE
+ * training hot path.
+ *
+ * The reference (neurospin-projects/2022_cambroise_interpret_multivae) is pure
+ * Python and has no FFI of its own; the entry points below are what a ctypes
+ * binding for its hot path binds (INTEGRATION.md shows the stub).  Each one
+ * names the reference interface it replaces (paths relative to the
+ * reference's experiments/ directory).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to float32 / int32 unless it is the
+ *     descriptor struct itself (host memory, read during the call only);
+ *   - all matrices are row-major; weights are (out, in) as in torch.nn.Linear;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); the
+ *     library never synchronises, allocates or frees device memory, so every
+ *     call is legal inside hipStreamBeginCapture / torch.cuda.graph;
+ *   - return 0 on success, MOPOE_ERR_ARG (-1) for a rejected descriptor,
+ *     MOPOE_ERR_HIP (-2) for a HIP runtime error; mopoe_last_error() returns
+ *     a thread-local message for the last non-zero return.
+ */
+#ifndef MOPOE_HIP_H
+#define MOPOE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOPOE_ABI_VERSION 1
+#define MOPOE_MAX_MODS 5      /* modalities                                   */
+#define MOPOE_MAX_SUBSETS 31  /* 2^MAX_MODS - 1 non-empty subsets             */
+#define MOPOE_MAX_JOBS 10     /* decoder passes: 1 joint + 1 unimodal per mod */
+#define MOPOE_HIDDEN 256      /* networks/networks.py:14,50 (hard-coded)      */
+#define MOPOE_ROWS 16         /* batch rows per workgroup tile (one MFMA M)   */
+
+#define MOPOE_ERR_ARG (-1)
+#define MOPOE_ERR_HIP (-2)
+
+/* sub_kind: how a subset's (mu, logvar) is formed
+ * (utils/BaseMMVae.py:43-61,96-122) */
+#define MOPOE_SUB_POE 0        /* product of experts, no prior expert          */
+#define MOPOE_SUB_POE_PRIOR 1  /* product of experts + N(0,1) prior expert     */
+#define MOPOE_SUB_SLICES 2     /* moe_fusion: contiguous row slices of members */
+
+/* joint_mode: BaseMMVae.inference (utils/BaseMMVae.py:226-231) */
+#define MOPOE_JOINT_MIXTURE 0  /* sample=True: mixture_component_selection     */
+#define MOPOE_JOINT_MEAN 1     /* sample=False: mean of mus and of logvars     */
+#define MOPOE_JOINT_EXPERT 2   /* use_expert=<subset key>                      */
+
+/* indices into the stats buffer written by every step (float32) */
+#define MOPOE_STAT_TOTAL_LOSS 0
+#define MOPOE_STAT_JOINT_DIV 1
+#define MOPOE_STAT_KLD_SUBSET 2                        /* + subset index       */
+#define MOPOE_STAT_KLD_STYLE (2 + MOPOE_MAX_SUBSETS)   /* + modality index     */
+#define MOPOE_STAT_NLL (MOPOE_STAT_KLD_STYLE + MOPOE_MAX_MODS) /* + job index  */
+#define MOPOE_NUM_STATS (MOPOE_STAT_NLL + MOPOE_MAX_JOBS)
+
+/* ---------------------------------------------------------------------------
+ * Model description: replaces the flags the reference's Encoder / Decoder /
+ * BaseMMVae constructors read (multimodal_cohort/networks/networks.py:9-28,
+ * 44-64; utils/BaseMMVae.py:17-34).  One hidden encoder layer of 256 units
+ * with ReLU, no hidden decoder layer (workflow.py:41-49 defaults).
+ *
+ * Flat parameter buffer layout (float32, every segment 64-float aligned), per
+ * modality m:
+ *   w1  (256, d_m)      encoders.<m>.shared_encoder.0.weight
+ *   b1  (256)           encoders.<m>.shared_encoder.0.bias
+ *   wh  (nh_m, 256)     rows: style_mu | style_logvar | class_mu | class_logvar
+ *   bh  (nh_m)          same order;  nh_m = 2*style_dim[m] + 2*class_dim
+ *   wd  (d_m, zd_m)     decoders.<m>.out_mu.weight, zd_m = style_dim[m]+class_dim
+ *   bd  (d_m)           decoders.<m>.out_mu.bias
+ *   lvo (d_m)           decoders.<m>.logvar  (1, d_m)
+ * ------------------------------------------------------------------------- */
+typedef struct mopoe_model {
+    int32_t num_mods;
+    int32_t class_dim;
+    int32_t input_dim[MOPOE_MAX_MODS];
+    int32_t style_dim[MOPOE_MAX_MODS]; /* 0 = no style branch                  */
+    int32_t learn_output_scale;        /* decoders.<m>.logvar trainable        */
+    /* filled by mopoe_model_layout(): offsets in floats into the flat buffer  */
+    int32_t off_w1[MOPOE_MAX_MODS];
+    int32_t off_b1[MOPOE_MAX_MODS];
+    int32_t off_wh[MOPOE_MAX_MODS];
+    int32_t off_bh[MOPOE_MAX_MODS];
+    int32_t off_wd[MOPOE_MAX_MODS];
+    int32_t off_bd[MOPOE_MAX_MODS];
+    int32_t off_lvo[MOPOE_MAX_MODS];
+    int32_t num_floats;                /* length of the flat buffer            */
+} mopoe_model;
+
+/* Fills the off_* fields and num_floats from the dims. */
+int mopoe_model_layout(mopoe_model* model);
+
+/* ---------------------------------------------------------------------------
+ * Step description: what BaseMMVae.inference / forward and
+ * run_epochs.basic_routine_epoch derive from the batch and the flags
+ * (utils/BaseMMVae.py:137-239, run_epochs.py:73-135, utils/utils.py:58-112).
+ * Built on the host by the Python side (plan.py); all float32 host arithmetic
+ * the reference performs (weights 1/K, floor(N*w) slice sizes) is done there
+ * and handed over as numbers.
+ * ------------------------------------------------------------------------- */
+typedef struct mopoe_step {
+    int32_t n;              /* batch rows                                      */
+    int32_t present_mask;   /* bit m: modality m is in the batch               */
+    int32_t sample;         /* sample_latents                                  */
+    int32_t joint_mode;     /* MOPOE_JOINT_*                                   */
+    int32_t expert_subset;  /* subset index for MOPOE_JOINT_EXPERT             */
+    int32_t backward;       /* also compute gradients (training step)          */
+
+    /* non-empty subsets in BaseExperiment.set_subsets order
+     * (utils/BaseExperiment.py:58-79) */
+    int32_t num_subsets;
+    uint8_t sub_mask[MOPOE_MAX_SUBSETS];   /* member bitmask                   */
+    uint8_t sub_avail[MOPOE_MAX_SUBSETS];  /* all members present              */
+    uint8_t sub_kind[MOPOE_MAX_SUBSETS];   /* MOPOE_SUB_*                      */
+    uint8_t sub_members[MOPOE_MAX_SUBSETS][MOPOE_MAX_MODS]; /* sorted-name order */
+    int32_t sub_f[MOPOE_MAX_SUBSETS];      /* SLICES: rows per member slice    */
+    float sub_kl_coef[MOPOE_MAX_SUBSETS];  /* d loss / d KL(subset)            */
+
+    /* mixture components = subsets passing fusion_condition
+     * (utils/BaseMMVae.py:125-134,213-227); comp_f = int(floor(N*w_0)) */
+    int32_t num_comp;
+    uint8_t comp_sub[MOPOE_MAX_SUBSETS];
+    int32_t comp_f;
+    float comp_w[MOPOE_MAX_SUBSETS];       /* reweighted weights (float32)     */
+
+    float style_kl_coef[MOPOE_MAX_MODS];   /* d loss / d KL(style_m)           */
+
+    /* decoder jobs: job 0.. = joint pass (one per present modality); method
+     * poe adds one unimodal job per present modality (run_epochs.py:104-128) */
+    int32_t num_jobs;
+    uint8_t job_mod[MOPOE_MAX_JOBS];
+    uint8_t job_slot[MOPOE_MAX_JOBS];      /* row block inside z/loc/g_xhat    */
+    int8_t job_src[MOPOE_MAX_JOBS];        /* -1: joint latent, else subset    */
+    uint8_t job_stream[MOPOE_MAX_JOBS];    /* pass id, non-decreasing; jobs of
+                                              a pass share the content eps    */
+    float job_nll_coef[MOPOE_MAX_JOBS];    /* d loss / d nll(job)              */
+
+    /* noise: injected eps (parity runs) or NULL -> on-device Philox4x32-10   */
+    const float* job_eps_content[MOPOE_MAX_JOBS]; /* (n, class_dim)            */
+    const float* job_eps_style[MOPOE_MAX_JOBS];   /* (n, style_dim[m])         */
+    uint64_t seed;
+} mopoe_step;
+
+/* ---------------------------------------------------------------------------
+ * Buffers.  Caller-owned (PyTorch caching allocator).  Row-major float32.
+ *   R_m = (number of jobs of modality m) * n   rows for the per-job tensors.
+ * ------------------------------------------------------------------------- */
+typedef struct mopoe_buffers {
+    float* params;                       /* (num_floats)                       */
+    float* grads;                        /* (num_floats)  written by backward  */
+    float* exp_avg;                      /* (num_floats)  Adam m               */
+    float* exp_avg_sq;                   /* (num_floats)  Adam v               */
+    int32_t* counters;                   /* [0] steps begun, [1] steps done    */
+
+    const float* x[MOPOE_MAX_MODS];      /* (rows, d_m) input, ld = d_m        */
+    const int32_t* row_index;            /* optional (n): x row of batch row   */
+
+    float* hidden[MOPOE_MAX_MODS];       /* (n, 256)     relu(x W1^T + b1)     */
+    float* heads[MOPOE_MAX_MODS];        /* (n, nh_m)    encoder outputs       */
+    float* subsets_mu;                   /* (num_subsets, n, D)                */
+    float* subsets_logvar;               /* (num_subsets, n, D)                */
+    float* joint_mu;                     /* (n, D)                             */
+    float* joint_logvar;                 /* (n, D)                             */
+    float* z[MOPOE_MAX_MODS];            /* (R_m, ldz_m) [style | content]     */
+    float* loc[MOPOE_MAX_MODS];          /* (R_m, d_m)   decoder mean          */
+    float* stats;                        /* (MOPOE_NUM_STATS)                  */
+
+    float* g_xhat[MOPOE_MAX_MODS];       /* (R_m, d_m)   d loss / d loc        */
+    float* g_heads[MOPOE_MAX_MODS];      /* (n, nh_m)                          */
+    float* g_pre[MOPOE_MAX_MODS];        /* (n, 256)     d loss / d pre-relu   */
+    float* partials;                     /* (tiles, mopoe_partials_stride())   */
+} mopoe_buffers;
+
+typedef struct mopoe_adam {
+    float lr, beta1, beta2, eps;         /* experiment.py:268-271              */
+} mopoe_adam;
+
+int mopoe_abi_version(void);
+const char* mopoe_last_error(void);
+/* sizeof / offsetof probes so a binding can verify its struct mirrors:
+ * 0 mopoe_model, 1 mopoe_step, 2 mopoe_buffers, 3 mopoe_adam (sizes);
+ * 4 step.job_eps_content, 5 step.comp_w, 6 buffers.partials,
+ * 7 model.num_floats (offsets); -1 otherwise. */
+int mopoe_sizeof(int which);
+
+/* leading dimension (floats) of z[m]: round_up(zd_m, 4) */
+int mopoe_ldz(const mopoe_model* model, int mod);
+/* floats per row-tile in `partials` */
+int mopoe_partials_stride(const mopoe_model* model);
+/* bytes of LDS the fused latent kernel needs for this model (<= 160 KiB) */
+int mopoe_latent_lds_bytes(const mopoe_model* model, const mopoe_step* step);
+
+/* Replaces BaseMMVae.forward / inference under torch.no_grad()
+ * (utils/BaseMMVae.py:137-239) plus the scalar terms of
+ * run_epochs.basic_routine_epoch (run_epochs.py:73-135): encoder, subset
+ * fusion, joint latent, reparameterisation, decoder, NLL and KL terms ->
+ * hidden, heads, subsets_*, joint_*, z, loc, stats. */
+int mopoe_forward(const mopoe_model* model, const mopoe_step* step,
+                  const mopoe_buffers* buf, void* stream);
+
+/* Replaces one iteration of run_epochs.train (run_epochs.py:158-184):
+ * basic_routine_epoch + total_loss.backward() [+ optimizer.step() when
+ * `adam` is non-NULL; pass NULL to stop after the gradients, e.g. to
+ * all-reduce buf->grads across ranks before mopoe_adam_step]. */
+int mopoe_train_step(const mopoe_model* model, const mopoe_step* step,
+                     const mopoe_buffers* buf, const mopoe_adam* adam,
+                     void* stream);
+
+/* Replaces torch.optim.Adam.step (experiment.py:256-279) on the flat buffer,
+ * restricted to the segments of the modalities in present_mask (parameters
+ * whose .grad is None are skipped by torch).  `grad_scale` multiplies the
+ * gradient first (1/world_size after a sum all-reduce).  The step number t
+ * is read from buf->counters[0]. */
+int mopoe_adam_step(const mopoe_model* model, int32_t present_mask,
+                    const mopoe_buffers* buf, const mopoe_adam* adam,
+                    float grad_scale, void* stream);
+
+/* Free functions of section 8b, float32 device tensors. */
+
+/* torch.nn.Linear (+ optional ReLU) as used by Encoder.forward / Decoder.forward
+ * (multimodal_cohort/networks/networks.py:30-36,66-77):
+ * y (n, ncols) = act(x (n, k) @ w (ncols, k)^T + b). */
+int mopoe_linear(const float* x, int32_t n, int32_t k, const float* w,
+                 const float* b, int32_t ncols, int32_t relu, float* y,
+                 void* stream);
+
+/* divergence_measures/mm_div.py:13-20  poe(mu, logvar, eps): (E,n,d)->(n,d) */
+int mopoe_poe(const float* mu, const float* logvar, int32_t num_experts,
+              int64_t numel, float eps, float* out_mu, float* out_logvar,
+              void* stream);
+/* divergence_measures/kl_div.py:7-14  calc_kl_divergence(mu0, logvar0,
+ * norm_value): scalar; `scratch` holds >= 1024 floats. */
+int mopoe_kl_divergence(const float* mu, const float* logvar, int64_t numel,
+                        float norm_value, float* scratch, float* out,
+                        void* stream);
+/* utils/BaseMMVae.py:37-40  reparameterize: out = eps * exp(0.5*logvar) + mu */
+int mopoe_reparameterize(const float* mu, const float* logvar,
+                         const float* eps, int64_t numel, uint64_t seed,
+                         uint64_t stream_id, float* out, void* stream);
+/* utils/utils.py:63-85  mixture_component_selection with host-computed slice
+ * starts (K+1 ints, device): (K,n,d) -> (n,d) */
+int mopoe_mixture_select(const float* mus, const float* logvars,
+                         int32_t num_comp, int32_t n, int32_t d,
+                         const int32_t* bounds, float* out_mu,
+                         float* out_logvar, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOPOE_HIP_H */
