@@ -24,6 +24,7 @@ STAT_KLD_SUBSET = 2
 STAT_KLD_STYLE = 2 + MAX_SUBSETS
 STAT_NLL = STAT_KLD_STYLE + MAX_MODS
 NUM_STATS = STAT_NLL + MAX_JOBS
+KERNEL_NAMES = ("k_linear", "k_latent", "k_wgrad", "k_adam", "k_finalize")
 
 _i32 = C.c_int32
 _u8 = C.c_uint8
@@ -118,6 +119,8 @@ SYMBOLS = {
     "mopoe_abi_version": (C.c_int, []),
     "mopoe_last_error": (C.c_char_p, []),
     "mopoe_sizeof": (C.c_int, [C.c_int]),
+    "mopoe_profile_enable": (C.c_int, [C.c_int]),
+    "mopoe_profile_read": (C.c_int, [C.POINTER(_i32), C.POINTER(_f32)]),
     "mopoe_model_layout": (C.c_int, [C.POINTER(Model)]),
     "mopoe_ldz": (C.c_int, [C.POINTER(Model), C.c_int]),
     "mopoe_partials_stride": (C.c_int, [C.POINTER(Model)]),
@@ -188,6 +191,19 @@ def require_gpu(t=None):
                          "CPU fallback")
     if t is not None and not t.is_cuda:
         raise MopoeError("expected a device tensor, got %s" % t.device)
+
+
+def profile_enable(on):
+    check(lib.mopoe_profile_enable(int(bool(on))), "mopoe_profile_enable")
+
+
+def profile_read():
+    """{kernel name: (launches, total ms)} since the last read."""
+    n = len(KERNEL_NAMES)
+    count = (_i32 * n)()
+    ms = (_f32 * n)()
+    check(lib.mopoe_profile_read(count, ms), "mopoe_profile_read")
+    return {KERNEL_NAMES[k]: (int(count[k]), float(ms[k])) for k in range(n)}
 
 
 def stream_ptr():

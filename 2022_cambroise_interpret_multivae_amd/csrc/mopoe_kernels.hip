@@ -20,6 +20,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "mopoe_common.h"
 
 namespace {
@@ -972,6 +974,44 @@ int fail(int code, const char* fmt, const char* arg = "") {
     return code;
 }
 
+// ---- optional per-kernel timing with HIP events on the launch stream -------
+struct ProfRec {
+    int kernel;
+    hipEvent_t beg, end;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;          // recorded, not yet read
+std::vector<hipEvent_t> g_prof_pool;  // free events
+
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) {
+        hipEvent_t e = g_prof_pool.back();
+        g_prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {  // records an event pair around one launch when enabled
+    hipStream_t s;
+    ProfRec r;
+    bool on;
+    ProfScope(int kernel, hipStream_t st) : s(st), on(g_prof_on) {
+        if (!on) return;
+        r.kernel = kernel;
+        r.beg = prof_event();
+        r.end = prof_event();
+        (void)hipEventRecord(r.beg, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.end, s);
+        g_prof.push_back(r);
+    }
+};
+
 int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -1056,8 +1096,11 @@ int latent_lds_bytes(const mopoe_model& mdl, const mopoe_step& st) {
 int launch_linear(const LinArgs& la, int max_k, int max_cols, hipStream_t s) {
     const int kp = round_up(max_k < kEncKChunk ? max_k : kEncKChunk, 16);
     const size_t lds = (size_t)kRows * (kp + 4) * sizeof(float);
-    hipLaunchKernelGGL(k_linear, dim3(cdiv(max_cols, 64), cdiv(la.n, kRows), la.ngroups),
-                       dim3(256), lds, s, la);
+    {
+        ProfScope ps(MOPOE_KERNEL_LINEAR, s);
+        hipLaunchKernelGGL(k_linear, dim3(cdiv(max_cols, 64), cdiv(la.n, kRows), la.ngroups),
+                           dim3(256), lds, s, la);
+    }
     return check_launch("k_linear");
 }
 
@@ -1097,7 +1140,10 @@ int launch_forward_part(const KArgs& ka, hipStream_t s) {
         if (e != hipSuccess) return fail(MOPOE_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         lds_opted = lds;
     }
-    hipLaunchKernelGGL(k_latent, dim3(tiles), dim3(kLatentThreads), (size_t)lds, s, ka);
+    {
+        ProfScope ps(MOPOE_KERNEL_LATENT, s);
+        hipLaunchKernelGGL(k_latent, dim3(tiles), dim3(kLatentThreads), (size_t)lds, s, ka);
+    }
     return check_launch("k_latent");
 }
 
@@ -1172,6 +1218,32 @@ int mopoe_model_layout(mopoe_model* mdl) {
     return 0;
 }
 
+int mopoe_profile_enable(int enable) {
+    g_prof_on = enable != 0;
+    return 0;
+}
+
+int mopoe_profile_read(int32_t* count, float* total_ms) {
+    if (!count || !total_ms) return fail(MOPOE_ERR_ARG, "mopoe_profile_read: null%s");
+    for (int k = 0; k < MOPOE_NUM_KERNELS; ++k) {
+        count[k] = 0;
+        total_ms[k] = 0.f;
+    }
+    for (const ProfRec& r : g_prof) {
+        hipError_t e = hipEventSynchronize(r.end);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.beg, r.end);
+        if (e != hipSuccess)
+            return fail(MOPOE_ERR_HIP, "mopoe_profile_read: %s", hipGetErrorString(e));
+        count[r.kernel] += 1;
+        total_ms[r.kernel] += ms;
+        g_prof_pool.push_back(r.beg);
+        g_prof_pool.push_back(r.end);
+    }
+    g_prof.clear();
+    return 0;
+}
+
 int mopoe_sizeof(int which) {
     switch (which) {
         case 0: return (int)sizeof(mopoe_model);
@@ -1205,7 +1277,10 @@ int mopoe_forward(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buff
     latent_lds_layout(ka.mdl, ka.st, kLatentWaves, ka.lds);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = launch_forward_part(ka, s)) return rc;
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, ka);
+    {
+        ProfScope ps(MOPOE_KERNEL_FINALIZE, s);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, ka);
+    }
     return check_launch("k_finalize");
 }
 
@@ -1225,7 +1300,11 @@ int mopoe_train_step(const mopoe_model* mdl, const mopoe_step* st, const mopoe_b
     if (int rc = launch_forward_part(ka, s)) return rc;
     WArgs w;
     build_wargs(ka, adam, w);
-    hipLaunchKernelGGL(k_wgrad, dim3(w.total_tiles + w.lvo_blocks + 1), dim3(256), 0, s, ka, w);
+    {
+        ProfScope ps(MOPOE_KERNEL_WGRAD, s);
+        hipLaunchKernelGGL(k_wgrad, dim3(w.total_tiles + w.lvo_blocks + 1), dim3(256), 0, s, ka,
+                           w);
+    }
     return check_launch("k_wgrad");
 }
 
@@ -1247,8 +1326,11 @@ int mopoe_adam_step(const mopoe_model* mdl, int32_t present_mask, const mopoe_bu
     if (sg.nseg == 0) return fail(MOPOE_ERR_ARG, "empty present_mask%s");
     sg.grad_scale = grad_scale;
     sg.adam = *adam;
-    hipLaunchKernelGGL(k_adam, dim3(128, sg.nseg), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), *buf, sg);
+    {
+        ProfScope ps(MOPOE_KERNEL_ADAM, static_cast<hipStream_t>(stream));
+        hipLaunchKernelGGL(k_adam, dim3(128, sg.nseg), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), *buf, sg);
+    }
     return check_launch("k_adam");
 }
 

@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py -- training samples/sec of the MoPoE-VAE hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted
+on): 2-modality joint_elbo MoPoE, input dims 7+444, latent 20, factorized
+style dims [3,20], batch 256 per GPU, float32 (exact-f32 MFMA), synthetic
+N(0,1) data -- a pool of 64 batches resident in HBM before the timed region
+-- random-init weights.  One step = encoder/decoder forward, MoPoE fusion,
+joint ELBO, full backward, (gradient all-reduce over RCCL when N > 1), Adam,
+and an asynchronous D2H copy of the step's scalar log (the reference logs
+every step, run_epochs.py:184).
+
+For N > 1 the driver launches one rank per GPU with torch.distributed.run;
+ranks are data-parallel replicas (weak scaling: 256 samples per GPU per
+step) and all-reduce the flat gradient buffer once per step.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the largest
+share of device time, its duration measured with HIP events on the launch
+stream in a second, instrumented run of the same K steps (events perturb the
+pipeline, so they stay out of the timed region that produces `value`).
+`cpu_baseline` times the CPU oracle (oracle/mopoe_oracle.py, a PyTorch-CPU
+restatement of the reference step) on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import mopoe_amd as mm  # noqa: E402
+
+NAMES = ["clinical", "rois"]
+DIMS = [7, 444]
+STYLE = [3, 20]
+LATENT = 20
+BATCH = 256
+POOL = 64
+HIDDEN = 256
+# MI355X_MICROARCH.md: exact-f32 MFMA peak = vector peak; HBM3E spec
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def kernel_models(spec, n, fused_adam):
+    """Algorithmic flops / HBM bytes per launch of each kernel at batch n
+    (DESIGN.md section 5 derives these from SURVEY.md section 8d)."""
+    M = spec.num_mods
+    d = sum(spec.input_dim)
+    nh = sum(spec.heads_dim(m) for m in range(M))
+    dz = sum(spec.input_dim[m] * spec.z_dim(m) for m in range(M))
+    zd = sum(spec.z_dim(m) for m in range(M))
+    P = sum(v.numel() for v in spec.param_views(
+        torch.empty(spec.num_floats)).values())
+    D = spec.class_dim
+    S = len(spec.subset_keys)
+    f = 4
+    out = {}
+    # h = relu(x W1^T + b1): read x and W1, write h
+    out["k_linear"] = dict(
+        flops=2.0 * n * HIDDEN * d,
+        bytes=f * (n * d + HIDDEN * d + HIDDEN * M + n * HIDDEN * M))
+    # heads, decoder, d/dz, d/dh GEMMs; reads h, x, Wh, Wd; writes heads,
+    # subsets, joint, z, loc, g_xhat, g_heads, g_pre
+    out["k_latent"] = dict(
+        flops=2.0 * n * (2 * HIDDEN * nh + 2 * dz),
+        bytes=f * (n * (2 * HIDDEN * M          # h read (+ mask re-read)
+                        + d                      # x
+                        + 2 * nh                 # heads, g_heads
+                        + 2 * S * D + 2 * D      # subsets, joint
+                        + zd + 2 * d             # z, loc, g_xhat
+                        + HIDDEN * M)            # g_pre
+                   + 2 * (HIDDEN * nh + dz) + nh + 3 * d))
+    # G^T X for W1, Wh, Wd (+ biases) and the Adam read-modify-write
+    wbytes = f * (n * (2 * HIDDEN * M + 2 * d + nh + zd) + P)
+    if fused_adam:
+        wbytes += f * 6 * P
+    out["k_wgrad"] = dict(flops=2.0 * n * (HIDDEN * d + HIDDEN * nh + dz),
+                          bytes=wbytes)
+    out["k_adam"] = dict(flops=0.0, bytes=f * 7 * P)
+    out["k_finalize"] = dict(flops=0.0, bytes=0.0)
+    return out
+
+
+def make_pool(device):
+    g = torch.Generator().manual_seed(1234)
+    pool = []
+    for _ in range(POOL):
+        pool.append({n: torch.randn(BATCH, d, generator=g).to(device)
+                     for n, d in zip(NAMES, DIMS)})
+    return pool
+
+
+def cpu_baseline(seconds=12.0):
+    """The oracle's train step (forward, loss, autograd backward, Adam) on the
+    host cores: a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mopoe_oracle as mo
+    cfg = mo.Config(NAMES, DIMS, STYLE, class_dim=LATENT)
+    params = mo.init_params(cfg, 0)
+    state = mo.adam_init(params)
+    g = torch.Generator().manual_seed(1234)
+    pool = [{n: torch.randn(BATCH, d, generator=g) for n, d in zip(NAMES, DIMS)}
+            for _ in range(8)]
+    noise = mo.Noise(generator=mo.noise_rng(0))
+    for i in range(5):
+        mo.train_step(params, cfg, pool[i % 8], noise, state)
+        noise.tape.clear()
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < seconds:
+        mo.train_step(params, cfg, pool[steps % 8], noise, state)
+        noise.tape.clear()
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(BATCH * steps / dt, 1), "unit": "samples/s",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d steps of the same bs-%d joint_elbo step (oracle/"
+                      "mopoe_oracle.py, PyTorch CPU float32, %d threads) in "
+                      "%.1f s" % (steps, BATCH, torch.get_num_threads(), dt),
+            "ms_per_step": round(1e3 * dt / steps, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-log-copy", action="store_true",
+                    help="leave the per-step async D2H of the scalar log out")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with "
+                     "torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    spec = mm.ModelSpec(NAMES, DIMS, STYLE, class_dim=LATENT, method="joint_elbo")
+    eng = mm.MoPoEEngine(spec, device, seed=1234)
+    eng.reset_parameters(torch.Generator().manual_seed(0))  # same on all ranks
+    pool = make_pool(device)
+    log_ring = [torch.empty(mm._lib.NUM_STATS, dtype=torch.float32).pin_memory()
+                for _ in range(8)]
+    fused = world == 1
+
+    def step(i):
+        plan, ws = eng.train_step(pool[(i * world + rank) % POOL],
+                                  apply_adam=fused)
+        if not fused:
+            dist.all_reduce(eng.grads)              # RCCL, one flat buffer
+            eng.adam_step(grad_scale=1.0 / world)
+        if not args.no_log_copy:
+            log_ring[i % 8].copy_(ws.stats, non_blocking=True)
+        return ws
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ws = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(ws.stats[0].item())
+    if not (loss == loss and abs(loss) < 1e9):
+        sys.exit("non-finite loss after the timed region: %r" % loss)
+
+    out = {
+        "metric": "training samples/sec (whole node), MoPoE joint_elbo, "
+                  "dims 7+444, bs256",
+        "value": round(BATCH * world * args.steps / dt, 1),
+        "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: 2-modality joint_elbo MoPoE-VAE "
+                               "train step, input_dims 7,444, latent 20, "
+                               "style 3,20, batch 256 per GPU, Adam lr 0.002",
+                   "global_batch": BATCH * world,
+                   "parallelism": "dp%d" % world if world > 1 else "single",
+                   "log_copy_every_step": not args.no_log_copy,
+                   "final_loss": round(loss, 3)},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # instrumented re-run of the same K steps: HIP events around every
+        # launch, on the launch stream
+        mm._lib.profile_enable(True)
+        for i in range(args.steps):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        prof = mm._lib.profile_read()
+        mm._lib.profile_enable(False)
+        models = kernel_models(spec, BATCH, fused)
+        total_ms = sum(ms for _, ms in prof.values()) or 1.0
+        name = max(prof, key=lambda k: prof[k][1])
+        cnt, ms = prof[name]
+        avg_s = ms / max(cnt, 1) * 1e-3
+        km = models[name]
+        t_mfma = km["flops"] / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        t_hbm = km["bytes"] / (PEAK_HBM_GBS * 1e9)
+        if t_mfma >= t_hbm:
+            achieved = km["flops"] / avg_s / 1e12
+            roof = {"bound": "mfma", "achieved": round(achieved, 4),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5)}
+        else:
+            achieved = km["bytes"] / avg_s / 1e9
+            roof = {"bound": "hbm", "achieved": round(achieved, 2),
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(achieved / PEAK_HBM_GBS, 5)}
+        roof.update({"traffic": None, "kernel": name,
+                     "avg_us": round(avg_s * 1e6, 3),
+                     "share_of_device_time": round(ms / total_ms, 3),
+                     "kernels_avg_us": {k: round(v[1] / max(v[0], 1) * 1e3, 3)
+                                        for k, v in prof.items() if v[0]},
+                     "algorithmic_flops": km["flops"],
+                     "algorithmic_bytes": km["bytes"]})
+        out["roofline"] = roof
+    elif dist is not None and not args.no_roofline:
+        for i in range(args.steps):   # keep the collectives matched
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

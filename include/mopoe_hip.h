@@ -178,6 +178,20 @@ typedef struct mopoe_adam {
     float lr, beta1, beta2, eps;         /* experiment.py:268-271              */
 } mopoe_adam;
 
+/* Per-kernel timing for bench.py's roofline figure.  While enabled, every
+ * launch is bracketed by a hipEvent pair recorded on the launch stream (not
+ * legal during stream capture).  mopoe_profile_read waits for the recorded
+ * events, returns per-kernel launch counts and summed milliseconds
+ * (arrays of MOPOE_NUM_KERNELS) and clears the log. */
+#define MOPOE_KERNEL_LINEAR 0
+#define MOPOE_KERNEL_LATENT 1
+#define MOPOE_KERNEL_WGRAD 2
+#define MOPOE_KERNEL_ADAM 3
+#define MOPOE_KERNEL_FINALIZE 4
+#define MOPOE_NUM_KERNELS 5
+int mopoe_profile_enable(int enable);
+int mopoe_profile_read(int32_t* count, float* total_ms);
+
 int mopoe_abi_version(void);
 const char* mopoe_last_error(void);
 /* sizeof / offsetof probes so a binding can verify its struct mirrors:

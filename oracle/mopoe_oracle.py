@@ -60,6 +60,9 @@ class Config:
         self.lr = lr
         self.betas = betas
         self.adam_eps = adam_eps
+        # float32 is the reference's arithmetic; tests also run the oracle in
+        # float64 to measure how much float32 rounding alone moves a result
+        self.dtype = torch.float32
 
     @property
     def num_mods(self):
@@ -215,7 +218,7 @@ def mixture_component_selection(mus, logvars, w):
 def calc_group_divergence_moe(mus, logvars, weights, normalization):
     """experiments/divergence_measures/mm_div.py:92-111."""
     K = mus.shape[0]
-    klds = torch.zeros(K)
+    klds = torch.zeros(K, dtype=mus.dtype)
     for k in range(K):
         klds[k] = calc_kl_divergence(mus[k], logvars[k],
                                      norm_value=normalization)
@@ -269,6 +272,7 @@ class Noise:
         self.replay = tape is not None
         self.pos = 0
         self.gen = generator
+        self.dtype = torch.float32
 
     def draw(self, shape):
         if self.replay:
@@ -279,7 +283,7 @@ class Noise:
             eps = torch.from_numpy(self.gen.standard_normal(
                 tuple(shape)).astype(np.float32))
             self.tape.append(eps)
-        return eps
+        return eps.to(self.dtype)
 
 
 def reparameterize(mu, logvar, noise):
@@ -296,8 +300,9 @@ def _modality_fusion(cfg, mus, logvars):
     E, N, D = mus.shape
     if cfg.method in ("joint_elbo", "poe"):
         if cfg.method == "poe" or E == cfg.num_mods:
-            mus = torch.cat((mus, torch.zeros(1, N, D)), dim=0)
-            logvars = torch.cat((logvars, torch.zeros(1, N, D)), dim=0)
+            mus = torch.cat((mus, torch.zeros(1, N, D, dtype=mus.dtype)), dim=0)
+            logvars = torch.cat((logvars, torch.zeros(1, N, D, dtype=mus.dtype)),
+                                dim=0)
         return poe(mus, logvars)
     w = reweight_weights((1 / float(E)) * torch.ones(E))
     return mixture_component_selection(mus, logvars, w)
@@ -343,7 +348,7 @@ def inference(params, cfg, batch, sample=True, use_expert=None):
     mus = torch.stack(mus)
     logvars = torch.stack(logvars)
     K = mus.shape[0]
-    weights = (1 / float(K)) * torch.ones(K)
+    weights = (1 / float(K)) * torch.ones(K)   # float32 as in the reference
     if sample and use_expert is None:
         joint_mu, joint_logvar = mixture_component_selection(
             mus, logvars, reweight_weights(weights))
@@ -425,7 +430,7 @@ def calc_elbo(cfg, modality, recs, klds, present):
 def basic_routine_epoch(params, cfg, batch, noise):
     """experiments/run_epochs.py:73-135 (+ calc_log_probs :27-38, calc_klds
     :41-48, calc_klds_style :51-59, calc_style_kld :62-69)."""
-    batch = OrderedDict((k, v.float()) for k, v in batch.items())
+    batch = OrderedDict((k, v.to(cfg.dtype)) for k, v in batch.items())
     results = forward(params, cfg, batch, noise)
     log_probs = OrderedDict()
     weighted_log_prob = 0.0
@@ -521,8 +526,10 @@ def loss_and_grads(params, cfg, batch, noise):
     not take part (absent modality) get no entry in `grads` -- exactly the
     params whose .grad torch leaves as None, which Adam then skips."""
     leaves = OrderedDict()
+    noise.dtype = cfg.dtype
     for k, v in params.items():
-        leaves[k] = v.detach().clone().requires_grad_(trainable(cfg, k))
+        leaves[k] = v.detach().to(cfg.dtype).clone().requires_grad_(
+            trainable(cfg, k))
     out = basic_routine_epoch(leaves, cfg, batch, noise)
     out["total_loss"].backward()
     grads = OrderedDict((k, v.grad) for k, v in leaves.items()

@@ -41,6 +41,14 @@ class Report:
                     float(g.reshape(-1)[i]), float(w.reshape(-1)[i]),
                     int((err > tol).sum()), g.numel()))
 
+    def close_scaled(self, name, got, want, scale_tol, rtol=0.0):
+        """|got - want| <= scale_tol * max|want| + rtol * |want|: the bound for
+        a float32 quantity that is a long signed sum (a gradient), whose
+        rounding error scales with the terms, not with the cancelled result."""
+        w = torch.as_tensor(want).detach().cpu().double()
+        atol = scale_tol * float(w.abs().max()) if w.numel() else 0.0
+        self.close(name, got, want, rtol, max(atol, 1e-12))
+
     def finish(self):
         if self.bad:
             raise AssertionError("%s: %d mismatching tensors\n  %s" % (
@@ -69,14 +77,17 @@ TOL = dict(
     latent=(2e-5, 2e-5),     # posterior mu / logvar, subsets, joint
     loc=(2e-5, 5e-5),        # reconstructions
     scalar=(2e-5, 1e-5),     # loss terms (values up to ~1e4)
-    grad=(2e-4, 2e-6),       # gradients
+    grad=4e-6,               # gradients: x max|g| of the tensor (the float32
+                             # oracle itself sits 4e-7..1e-6 x max|g| from a
+                             # float64 evaluation, tests/test_oracle_precision.py)
+    moment2=2e-5,            # Adam exp_avg_sq: x max of the tensor
     param1=(1e-5, 5e-6),     # parameters after one Adam step (lr 2e-3: a
                              # sign-level disagreement on a ~0 gradient moves
                              # a weight by up to 4e-3, handled separately)
 )
 
 
-def compare_forward(rep, spec, eng, plan, ws, out, prefix=""):
+def compare_forward(rep, spec, eng, plan, ws, out, prefix="", check_scale=True):
     """HIP results vs the oracle's basic_routine_epoch / forward output."""
     res_o = out["results"] if "results" in out else out
     lat_o = res_o["latents"]
@@ -103,8 +114,9 @@ def compare_forward(rep, spec, eng, plan, ws, out, prefix=""):
     assert list(res["rec"].keys()) == list(res_o["rec"].keys())
     for k, (loc, scale) in res_o["rec"].items():
         rep.close(prefix + "rec/%s/loc" % k, res["rec"][k].loc, loc, rt, at)
-        rep.close(prefix + "rec/%s/scale" % k, res["rec"][k].scale,
-                  scale.expand_as(loc), 1e-6, 1e-7)
+        if check_scale:  # (after a fused Adam step the logvar has moved on)
+            rep.close(prefix + "rec/%s/scale" % k, res["rec"][k].scale,
+                      scale.expand_as(loc), 1e-6, 1e-7)
     rt, at = TOL["scalar"]
     rep.close(prefix + "joint_divergence", res["joint_divergence"],
               res_o["joint_divergence"], rt, at)
