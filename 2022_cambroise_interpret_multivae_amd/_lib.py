@@ -112,7 +112,7 @@ class Adam(C.Structure):
 
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
-                        "libmopoe_hip.so")
+                        os.environ.get("MOPOE_LIB", "libmopoe_hip.so"))
 
 # every symbol include/mopoe_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {

@@ -39,11 +39,13 @@ HD int ld_z_lds(const mopoe_model& m, int i) { return round_up(z_dim(m, i), 16) 
 HD int ld_x_lds(const mopoe_model& m, int i) { return round_up(m.input_dim[i], 16) + 4; }
 
 // offset of modality i's logvar-gradient partials inside a row tile's slot
+constexpr int kLvoSlots = 2;  // decoder jobs per modality (joint + unimodal)
 HD int lvo_part_off(const mopoe_model& m, int i) {
     int off = kStatStride;
-    for (int k = 0; k < i; ++k) off += round_up(m.input_dim[k], 4);
+    for (int k = 0; k < i; ++k) off += kLvoSlots * round_up(m.input_dim[k], 4);
     return off;
 }
+HD int lvo_slot_stride(const mopoe_model& m, int i) { return round_up(m.input_dim[i], 4); }
 HD int partials_stride(const mopoe_model& m) { return lvo_part_off(m, m.num_mods); }
 
 // ---------------------------------------------------------------------------
@@ -127,72 +129,196 @@ DEV f32x4 lds_a4(const float* As, int lda, int kb, int lane) {
     return *reinterpret_cast<const f32x4*>(As + (lane & 15) * lda + kb + 4 * (lane >> 4));
 }
 
-// B fragment of Y = A * W^T: W is (ncols, K) row-major with row stride ldw.
-DEV f32x4 glb_b4_nt(const float* __restrict__ W, int ldw, int ncols, int K, int j0,
-                    int kb, int lane, bool vec) {
+// ---------------------------------------------------------------------------
+// Global-memory reads of the hot loops go through buffer descriptors
+// (`buffer_load ... offen`): the hardware range check returns 0 for an offset
+// at or past num_records, so an out-of-range lane needs neither a branch nor a
+// select on the loaded value -- it is simply given the offset kOOB.  This keeps
+// every load of a batch in one basic block and in flight together.  (With plain
+// pointer loads hipcc turns `cond ? *p : 0` into a branch around the load and
+// drains the memory counter at every join: the batch serialises.)
+// Descriptors are built from wave-uniform values only (kernel arguments and
+// blockIdx-derived scalars), num_records is capped at 2 GiB - 1 so that kOOB
+// is always out of range.
+// ---------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOOB = 0x80000000u;
+
+DEV rsrc_t make_rsrc(const void* p, size_t bytes) {
+    // readfirstlane makes the uniformity provable to hipcc (guide T20); the
+    // inputs ARE wave-uniform at every call site
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    uint32_t n = bytes > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)bytes;
+    n = __builtin_amdgcn_readfirstlane(n);
+    void* q = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, n, 0x00020000);
+}
+DEV rsrc_t make_rsrc_max(const void* p) { return make_rsrc(p, 0x7FFFFFFFull); }
+// offset (< 2 GiB) of a lane, pushed out of range when the lane is invalid.
+// Written as arithmetic on purpose: a `ok ? off : kOOB` select invites hipcc to
+// split the two cases into branches again.
+DEV uint32_t guard(uint32_t byte_off, bool ok) { return byte_off | (ok ? 0u : kOOB); }
+DEV float ldg(rsrc_t r, uint32_t byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+DEV f32x4 ldg4(rsrc_t r, uint32_t byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
+// B fragment of Y = A * W^T: W is (ncols, K) row-major with row stride ldw;
+// r covers ncols * ldw floats, so col >= ncols is out of range by itself.
+// VEC: K % 4 == 0 (then a 4-wide read never crosses a row end).
+template <bool VEC>
+DEV f32x4 glb_b4_nt(rsrc_t r, int ldw, int K, int j0, int kb, int lane) {
     const int col = j0 + (lane & 15);
     const int k = kb + 4 * (lane >> 4);
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (col < ncols) {
-        const float* p = W + (size_t)col * ldw + k;
-        if (vec && k + 3 < K) {
-            v = *reinterpret_cast<const f32x4*>(p);
+    const uint32_t base = (uint32_t)(col * ldw + k) * 4u;
+    f32x4 v;
+    if (VEC) {
+        v = ldg4(r, guard(base, k < K));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ldg(r, guard(base + 4u * i, k + i < K));
+    }
+    return v;
+}
+
+// B fragment of Y = A * B: B is (K, ncols) row-major with row stride ldb;
+// r covers K * ldb floats, so k >= K is out of range by itself.
+DEV f32x4 glb_b4_nn(rsrc_t r, int ldb, int ncols, int j0, int kb, int lane) {
+    const int col = j0 + (lane & 15);
+    const int k = kb + 4 * (lane >> 4);
+    const uint32_t base = (uint32_t)(k * ldb + col) * 4u;
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        v[i] = ldg(r, guard(base + (uint32_t)(i * ldb) * 4u, col < ncols));
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Tile GEMM machinery.  One "unit" = one 16x16 output tile (or one K-slice of
+// it): A (16 x K, zero padded to a multiple of 16) sits in LDS, B is streamed
+// from global/L2 straight into registers -- each B element is used by exactly
+// one wave of the workgroup, so an LDS round trip would be pure overhead.
+// The step is latency-bound, so what matters is how many loads are in flight:
+// all B fragments of a batch (CH blocks of 16 k) are requested before the
+// first MFMA of the batch, and the NEXT unit's first batch (plus whatever its
+// epilogue will need from global memory) is requested before the current
+// unit's MFMAs start.
+// ---------------------------------------------------------------------------
+struct GemmUnit {
+    const float* As;  // LDS A tile [16][lda]
+    const float* B;   // global B operand
+    int lda, ldb, ncols, K, j0, kbeg, kend;
+    int vec;          // NT only: K % 4 == 0 (4-wide reads stay inside a row)
+    int tag, tag2;    // stage-specific
+};
+
+template <bool NT, int CH>
+DEV void load_batch(const GemmUnit& u, int kb, f32x4 (&b)[CH], int lane) {
+    if (NT) {
+        const rsrc_t r = make_rsrc(u.B, (size_t)u.ncols * u.ldb * sizeof(float));
+        if (u.vec) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                b[c] = glb_b4_nt<true>(r, u.ldb, u.K, u.j0, kb + 16 * c, lane);
         } else {
-            if (k < K) v[0] = p[0];
-            if (k + 1 < K) v[1] = p[1];
-            if (k + 2 < K) v[2] = p[2];
-            if (k + 3 < K) v[3] = p[3];
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                b[c] = glb_b4_nt<false>(r, u.ldb, u.K, u.j0, kb + 16 * c, lane);
         }
+    } else {
+        const rsrc_t r = make_rsrc(u.B, (size_t)u.K * u.ldb * sizeof(float));
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            b[c] = glb_b4_nn(r, u.ldb, u.ncols, u.j0, kb + 16 * c, lane);
     }
-    return v;
 }
 
-// B fragment of Y = A * B: B is (K, ncols) row-major with row stride ldb.
-DEV f32x4 glb_b4_nn(const float* __restrict__ B, int ldb, int ncols, int K, int j0,
-                    int kb, int lane) {
-    const int col = j0 + (lane & 15);
-    const int k = kb + 4 * (lane >> 4);
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (col < ncols) {
-        const float* p = B + (size_t)k * ldb + col;
-        if (k < K) v[0] = p[0];
-        if (k + 1 < K) v[1] = p[(size_t)ldb];
-        if (k + 2 < K) v[2] = p[(size_t)2 * ldb];
-        if (k + 3 < K) v[3] = p[(size_t)3 * ldb];
+template <int CH>
+DEV void mma_batch(const GemmUnit& u, int kb, const f32x4 (&b)[CH], f32x4& acc,
+                   f32x4& acc2, int lane) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int k = kb + 16 * c;
+        if (k < u.kend) {  // wave-uniform
+            const f32x4 a = lds_a4(u.As, u.lda, k, lane);
+            // two accumulators: the 16x16x4 f32 MFMA has a 40-cycle dependent
+            // latency against a 32-cycle issue interval
+            acc = mfma_16x16x4(a[0], b[c][0], acc);
+            acc2 = mfma_16x16x4(a[1], b[c][1], acc2);
+            acc = mfma_16x16x4(a[2], b[c][2], acc);
+            acc2 = mfma_16x16x4(a[3], b[c][3], acc2);
+        }
     }
-    return v;
 }
 
-// One 16x16 output tile, A (16 x K, zero padded to a multiple of 16) in LDS,
-// B streamed from global/L2 straight into registers (each B element is used by
-// exactly one wave of the workgroup, so an LDS round trip would be pure
-// overhead); next block's fragments are fetched ahead of the MFMAs.
-template <bool NT>
-DEV f32x4 tile_gemm(f32x4 acc, const float* As, int lda, const float* __restrict__ B,
-                    int ldb, int ncols, int K, int j0, int kbeg, int kend, int lane,
-                    bool vec) {
-    if (kbeg >= kend) return acc;
-    f32x4 a = lds_a4(As, lda, kbeg, lane);
-    f32x4 b = NT ? glb_b4_nt(B, ldb, ncols, K, j0, kbeg, lane, vec)
-                 : glb_b4_nn(B, ldb, ncols, K, j0, kbeg, lane);
-    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-    for (int kb = kbeg; kb < kend; kb += 16) {
-        f32x4 an = {0.f, 0.f, 0.f, 0.f}, bn = {0.f, 0.f, 0.f, 0.f};
-        if (kb + 16 < kend) {
-            an = lds_a4(As, lda, kb + 16, lane);
-            bn = NT ? glb_b4_nt(B, ldb, ncols, K, j0, kb + 16, lane, vec)
-                    : glb_b4_nn(B, ldb, ncols, K, j0, kb + 16, lane);
-        }
-        // two accumulators: the 16x16x4 f32 MFMA has a 40-cycle dependent
-        // latency against a 32-cycle issue interval
-        acc = mfma_16x16x4(a[0], b[0], acc);
-        acc2 = mfma_16x16x4(a[1], b[1], acc2);
-        acc = mfma_16x16x4(a[2], b[2], acc);
-        acc2 = mfma_16x16x4(a[3], b[3], acc2);
-        a = an;
-        b = bn;
+// Runs the units first, first+stride, ... of one wave.  get_unit(idx, unit)
+// fills the descriptor and returns false past the end; prefetch(unit) issues
+// the global loads the unit's epilogue will need and returns them; epilogue
+// (unit, acc, extra) consumes the finished tile.
+#ifdef MOPOE_STAMPS
+#define USTAMP(p, i) \
+    do { if (p) (p)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define USTAMP(p, i) do { } while (0)
+#endif
+
+template <bool NT, int CH, class Get, class Pre, class Epi>
+DEV void run_units(int first, int stride, int lane, Get get_unit, Pre prefetch,
+                   Epi epilogue, unsigned long long* sp = nullptr) {
+    GemmUnit cur, nxt;
+    int idx = first;
+    bool has = get_unit(idx, cur);
+    f32x4 b[CH];
+    using Extra = decltype(prefetch(cur));
+    Extra extra{};
+    USTAMP(sp, 0);
+    if (has) {
+        load_batch<NT, CH>(cur, cur.kbeg, b, lane);
+        extra = prefetch(cur);
     }
-    return acc + acc2;
+    USTAMP(sp, 1);
+    int ucount = 0;
+    while (has) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        Extra extran{};
+        bool hasn = false;
+        for (int kb = cur.kbeg;; kb += 16 * CH) {
+            const bool last = kb + 16 * CH >= cur.kend;
+            f32x4 bn[CH];
+            if (!last) {  // K longer than one batch: next batch of this unit
+                load_batch<NT, CH>(cur, kb + 16 * CH, bn, lane);
+            } else {      // next unit's first batch + what its epilogue needs
+                idx += stride;
+                hasn = get_unit(idx, nxt);
+                if (hasn) {
+                    load_batch<NT, CH>(nxt, nxt.kbeg, bn, lane);
+                    extran = prefetch(nxt);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) bn[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if (ucount == 0) USTAMP(sp, 2);
+            mma_batch<CH>(cur, kb, b, acc, acc2, lane);
+            if (ucount == 0) USTAMP(sp, 3);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) b[c] = bn[c];
+            if (last) break;
+        }
+        epilogue(cur, acc + acc2, extra);
+        if (ucount == 0) USTAMP(sp, 4);
+        ++ucount;
+        cur = nxt;
+        has = hasn;
+        extra = extran;
+    }
+    USTAMP(sp, 5);
 }
 
 // Philox4x32-10 -> one standard normal (Box-Muller).  Counter = (element,

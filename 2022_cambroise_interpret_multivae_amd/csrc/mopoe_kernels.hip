@@ -26,10 +26,29 @@
 
 namespace {
 
-constexpr int kLatentThreads = 512;
+constexpr int kLatentThreads = 1024;
 constexpr int kLatentWaves = kLatentThreads / kWave;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 constexpr float kPoeEps = 1e-8f;
+
+// Diagnostic build only (-DMOPOE_STAMPS, libmopoe_hip_stamps.so): lane 0 of
+// block 0 records (s_memrealtime [100 MHz], s_memtime [shader clock]) at stage
+// boundaries into the floats behind the stats (never read by the kernels).
+#ifdef MOPOE_STAMPS
+#define STAMP(buf, i)                                                              \
+    do {                                                                           \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                 \
+            unsigned long long* sp_ =                                              \
+                reinterpret_cast<unsigned long long*>((buf).stats + 64) + 2 * (i); \
+            sp_[0] = __builtin_amdgcn_s_memrealtime();                             \
+            sp_[1] = __builtin_amdgcn_s_memtime();                                 \
+        }                                                                          \
+    } while (0)
+#else
+#define STAMP(buf, i) \
+    do {              \
+    } while (0)
+#endif
 
 struct KArgs {
     mopoe_model mdl;
@@ -64,55 +83,142 @@ struct LinGroup {
 struct LinArgs {
     int32_t n;
     int32_t ngroups;
-    int32_t* bump;         // counter incremented once per launch, or nullptr
+    int32_t* counters;     // training step: bump [0], publish Adam coefficients
+    int32_t publish;       // adam is valid: publish its step coefficients
+    mopoe_adam adam;
     LinGroup g[MOPOE_MAX_MODS];
 };
 
+// Adam scalars of step t, torch.optim.Adam (_single_tensor_adam) semantics:
+// python-double scalars applied to float32 tensors.  Computed once per step by
+// one thread of the step's first kernel and published next to the counters.
+struct AdamCoef {
+    float b2, one_m_b1, one_m_b2, step_size, bc2_sqrt, eps, pad;
+};
+constexpr int kCoefTag = 3;   // counters[3]: step the coefficients belong to
+constexpr int kCoefBase = 4;  // counters[4..]: AdamCoef as float bits
+
+DEV AdamCoef adam_coef(const mopoe_adam& ad, int t) {
+    AdamCoef c;
+    const double b1 = (double)ad.beta1, b2 = (double)ad.beta2;
+    const double bc1 = 1.0 - pow(b1, (double)t);
+    const double bc2 = 1.0 - pow(b2, (double)t);
+    c.b2 = ad.beta2;
+    c.one_m_b1 = (float)(1.0 - b1);
+    c.one_m_b2 = (float)(1.0 - b2);
+    c.step_size = (float)((double)ad.lr / bc1);
+    c.bc2_sqrt = (float)sqrt(bc2);
+    c.eps = ad.eps;
+    c.pad = 0.f;
+    return c;
+}
+
+DEV AdamCoef adam_coef_load(const int32_t* counters, const mopoe_adam& ad) {
+    const int t = counters[0];
+    if (counters[kCoefTag] != t) return adam_coef(ad, t);  // not published
+    return *reinterpret_cast<const AdamCoef*>(counters + kCoefBase);
+}
+
+DEV void adam_update(const AdamCoef& c, float g, float p, float m, float v, float* po,
+                     float* mo, float* vo) {
+    const float m1 = m + c.one_m_b1 * (g - m);           // exp_avg.lerp_(g, 1-b1)
+    const float v1 = v * c.b2 + (c.one_m_b2 * g) * g;     // mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = sqrtf(v1) / c.bc2_sqrt + c.eps;
+    *mo = m1;
+    *vo = v1;
+    *po = p - c.step_size * (m1 / denom);                 // addcdiv_(m, denom, -step)
+}
+
 __global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave id as a provably wave-uniform scalar (guide T20): everything derived
+    // from it stays in SGPRs and buffer descriptors need no waterfall loop
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = a.n;
-    if (a.bump && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
-        *a.bump += 1;  // training step number t (read by Adam and Philox)
+    if (a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+        const int t = a.counters[0] + 1;  // training step number (Adam, Philox)
+        a.counters[0] = t;
+        if (a.publish) {
+            *reinterpret_cast<AdamCoef*>(a.counters + kCoefBase) = adam_coef(a.adam, t);
+            a.counters[kCoefTag] = t;
+        }
+    }
     const LinGroup& g = a.g[blockIdx.z];
     if ((int)blockIdx.x * 64 >= g.ncols) return;
     const int K = g.K;
-    const float* __restrict__ X = g.X;
-    const bool vecx = (g.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    const bool vecw = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.W) & 15) == 0);
+    const rsrc_t xr = make_rsrc_max(g.X);
+    const bool vecx = K % 4 == 0;   // 4-wide reads stay inside a row
+    const bool vecw = K % 4 == 0;
     const int n0 = blockIdx.y * kRows;
     const int j0 = (blockIdx.x * 4 + wave) * 16;
 
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // source row of each of the tile's 16 batch rows (gather resolved once)
+    __shared__ int rowsel[kRows];
+    if (tid < kRows) {
+        const int gn = min(n0 + tid, N - 1);
+        rowsel[tid] = g.rows ? g.rows[gn] : gn;
+    }
+    __syncthreads();
+    constexpr int CH = 8;     // W fragments per batch (8 x 16 k)
+    constexpr int kStage = 4;  // float4 loads in flight per thread while staging
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     for (int kc0 = 0; kc0 < K; kc0 += kEncKChunk) {
         const int Kc = min(kEncKChunk, K - kc0);
         const int Kp = round_up(Kc, 16);
         const int ldx = Kp + 4;
         const int q4 = Kp / 4;
+        GemmUnit u;
+        u.As = lds;
+        u.B = g.W + kc0;
+        u.lda = ldx;
+        u.ldb = K;
+        u.ncols = g.ncols;
+        u.K = Kc;
+        u.j0 = j0;
+        u.kbeg = 0;
+        u.kend = j0 < g.ncols ? Kp : 0;
+        u.vec = vecw;
+        // the wave's first batch of W fragments is in flight while the
+        // workgroup stages the input tile
+        f32x4 b[CH];
+        load_batch<true, CH>(u, 0, b, lane);
         if (kc0 > 0) __syncthreads();
-        for (int s = tid; s < kRows * q4; s += blockDim.x) {
-            const int r = s / q4, k = (s - r * q4) * 4;
-            const int gn = n0 + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gn < N) {
-                const int xr = g.rows ? g.rows[gn] : gn;
-                const float* p = X + (size_t)xr * g.ldx + kc0 + k;
-                if (vecx && k + 3 < Kc) {
-                    v = *reinterpret_cast<const f32x4*>(p);
+        for (int s0 = 0; s0 < kRows * q4; s0 += kStage * 256) {
+            f32x4 v[kStage];
+#pragma unroll
+            for (int i = 0; i < kStage; ++i) {
+                const int s = s0 + i * 256 + tid;
+                const int r = min(s / q4, kRows - 1), k = (s - (s / q4) * q4) * 4;
+                const bool rv = (s < kRows * q4) & (n0 + r < N);
+                const uint32_t base = (uint32_t)(rowsel[r] * g.ldx + kc0 + k) * 4u;
+                if (vecx) {
+                    v[i] = ldg4(xr, guard(base, rv & (k < Kc)));
                 } else {
-                    if (k < Kc) v[0] = p[0];
-                    if (k + 1 < Kc) v[1] = p[1];
-                    if (k + 2 < Kc) v[2] = p[2];
-                    if (k + 3 < Kc) v[3] = p[3];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[i][e] = ldg(xr, guard(base + 4u * e, rv & (k + e < Kc)));
                 }
             }
-            *reinterpret_cast<f32x4*>(lds + r * ldx + k) = v;
+#pragma unroll
+            for (int i = 0; i < kStage; ++i) {
+                const int s = s0 + i * 256 + tid;
+                if (s < kRows * q4) {
+                    const int r = s / q4, k = (s - r * q4) * 4;
+                    *reinterpret_cast<f32x4*>(lds + r * ldx + k) = v[i];
+                }
+            }
         }
         __syncthreads();
-        if (j0 < g.ncols)
-            acc = tile_gemm<true>(acc, lds, ldx, g.W + kc0, K, g.ncols, Kc, j0, 0, Kp, lane,
-                                  vecw);
+        for (int kb = 0; kb < u.kend; kb += 16 * CH) {
+            f32x4 bn[CH];
+            load_batch<true, CH>(u, kb + 16 * CH, bn, lane);  // clamped past the end
+            mma_batch<CH>(u, kb, b, acc, acc2, lane);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) b[c] = bn[c];
+        }
     }
+    acc += acc2;
     const int col = j0 + (lane & 15);
     if (col >= g.ncols) return;
     const float bias = g.b ? g.b[col] : 0.f;
@@ -207,61 +313,144 @@ __global__ __launch_bounds__(kLatentThreads) void k_latent(const KArgs a) {
     const mopoe_model& mdl = a.mdl;
     const mopoe_step& st = a.st;
     const mopoe_buffers& buf = a.buf;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave id as a provably wave-uniform scalar (guide T20): everything derived
+    // from it stays in SGPRs and buffer descriptors need no waterfall loop
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = st.n, D = mdl.class_dim, M = mdl.num_mods;
+    const float* __restrict__ P = buf.params;
+    const int row_tiles = cdiv(N, kRows);
+    if ((int)blockIdx.x >= row_tiles) {
+        // L2 warmers.  A kernel starts with cold per-XCD L2s, and a single CU
+        // streams misses at only ~20 GB/s, so a row-tile workgroup that has to
+        // pull every encoder-head / decoder weight (twice) through its own CU
+        // is bound by that.  These extra workgroups -- the otherwise idle CUs --
+        // touch one slice of the weights each; blocks b and b+8 share an XCD
+        // (round-robin dispatch, speed only), so slice s is touched once per
+        // XCD and the row-tile workgroups then stream L2 hits.
+        const int pb = (int)blockIdx.x - row_tiles;
+        const int nslices = max(((int)gridDim.x - row_tiles) / 8, 1);
+        const int slice = pb / 8;
+        float sink = 0.f;
+        for (int m = 0; m < M; ++m) {
+            if (!((st.present_mask >> m) & 1)) continue;
+            const int cnt[2] = {heads_dim(mdl, m) * kHid, mdl.input_dim[m] * z_dim(mdl, m)};
+            const int off[2] = {mdl.off_wh[m], mdl.off_wd[m]};
+            for (int w = 0; w < 2; ++w) {
+                const int per = round_up(cdiv(cnt[w], nslices), 32);  // 128-byte lines
+                const int beg = slice * per, end = min(beg + per, cnt[w]);
+                // one 4-byte read per 128-byte line
+                for (int i = beg + tid * 32; i < end; i += kLatentThreads * 32)
+                    sink += P[off[w] + i];
+            }
+        }
+        asm volatile("" ::"v"(sink));
+        return;
+    }
     const int n0 = blockIdx.x * kRows;
     const float inv_n = 1.0f / (float)N;
     const bool bwd = st.backward != 0;
     const bool sample = st.sample != 0;
     const uint32_t step_no = (uint32_t)buf.counters[0];
-    const float* __restrict__ P = buf.params;
 
     const LatentLds& L = a.lds;
     float* red = lds + L.red;
 
+    // source rows of this lane's four accumulator rows (clamped: see the
+    // no-conditional-loads rule in mopoe_common.h)
+    int xrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gn = n0 + 4 * (lane >> 4) + r;
+        xrow[r] = gn < N ? src_row(buf, gn) : -1;
+    }
+    const rsrc_t prsrc = make_rsrc(P, (size_t)mdl.num_floats * sizeof(float));
+
+    STAMP(buf, 0);
     // ---- S0: hidden tiles -> LDS, zero the reduction scratch ---------------
     for (int i = tid; i < kLatentWaves * kStatStride; i += kLatentThreads) red[i] = 0.f;
-    for (int m = 0; m < M; ++m) {
-        if (!((st.present_mask >> m) & 1)) continue;
-        const float* __restrict__ H = buf.hidden[m];
-        float* hs = lds + L.hs[m];
-        for (int s = tid; s < kRows * (kHid / 4); s += kLatentThreads) {
-            const int r = s / (kHid / 4), k = (s % (kHid / 4)) * 4;
-            const int gn = n0 + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gn < N) v = *reinterpret_cast<const f32x4*>(H + (size_t)gn * kHid + k);
-            *reinterpret_cast<f32x4*>(hs + r * kLdH + k) = v;
+    {
+        // 16 x 256 floats per modality = 2 float4 per thread; every load of
+        // every modality is issued before the first LDS store
+        constexpr int kPer = kRows * (kHid / 4) / kLatentThreads;
+        static_assert(kPer * kLatentThreads == kRows * (kHid / 4), "tile/threads");
+        f32x4 hv[MOPOE_MAX_MODS][kPer];
+#pragma unroll
+        for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
+            if (m < M && ((st.present_mask >> m) & 1)) {
+                const rsrc_t hr = make_rsrc(buf.hidden[m], (size_t)N * kHid * sizeof(float));
+#pragma unroll
+                for (int i = 0; i < kPer; ++i) {
+                    const int s = tid + i * kLatentThreads;
+                    const int r = s / (kHid / 4), k = (s % (kHid / 4)) * 4;
+                    hv[m][i] = ldg4(hr, (uint32_t)((n0 + r) * kHid + k) * 4u);  // 0 past N
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
+            if (m < M && ((st.present_mask >> m) & 1)) {
+#pragma unroll
+                for (int i = 0; i < kPer; ++i) {
+                    const int s = tid + i * kLatentThreads;
+                    const int r = s / (kHid / 4), k = (s % (kHid / 4)) * 4;
+                    *reinterpret_cast<f32x4*>(lds + L.hs[m] + r * kLdH + k) = hv[m][i];
+                }
+            }
         }
     }
     __syncthreads();
+    STAMP(buf, 1);
 
     // ---- S1: encoder heads [style_mu|style_lv|class_mu|class_lv] ----------
     {
-        int u = wave;
-        int base = 0;
-        for (int m = 0; m < M; ++m) {
-            if (!((st.present_mask >> m) & 1)) continue;
-            const int nh = heads_dim(mdl, m), tiles = cdiv(nh, 16);
-            const int ldh = ld_heads_lds(mdl, m);
-            for (; u < base + tiles; u += kLatentWaves) {
-                const int j0 = (u - base) * 16;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = tile_gemm<true>(acc, lds + L.hs[m], kLdH, P + mdl.off_wh[m], kHid,
-                                      nh, kHid, j0, 0, kHid, lane, true);
-                const int col = j0 + (lane & 15);
-                const float bias = col < nh ? P[mdl.off_bh[m] + col] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * (lane >> 4) + r, gn = n0 + row;
-                    const float v = col < nh ? acc[r] + bias : 0.f;
-                    lds[L.heads[m] + row * ldh + col] = v;
-                    if (col < nh && gn < N) buf.heads[m][(size_t)gn * nh + col] = v;
+        auto get = [&](int idx, GemmUnit& u) -> bool {
+            int base = 0;
+            for (int m = 0; m < M; ++m) {
+                if (!((st.present_mask >> m) & 1)) continue;
+                const int nh = heads_dim(mdl, m), tiles = cdiv(nh, 16);
+                if (idx < base + tiles) {
+                    u.As = lds + L.hs[m];
+                    u.B = P + mdl.off_wh[m];
+                    u.lda = kLdH;
+                    u.ldb = kHid;
+                    u.ncols = nh;
+                    u.K = kHid;
+                    u.j0 = (idx - base) * 16;
+                    u.kbeg = 0;
+                    u.kend = kHid;
+                    u.vec = 1;
+                    u.tag = m;
+                    return true;
                 }
+                base += tiles;
             }
-            base += tiles;
-        }
+            return false;
+        };
+        auto pre = [&](const GemmUnit& u) -> f32x4 {
+            const int col = u.j0 + (lane & 15);
+            f32x4 e = {0.f, 0.f, 0.f, 0.f};
+            e[0] = ldg(prsrc, guard((uint32_t)(mdl.off_bh[u.tag] + col) * 4u, col < u.ncols));
+            return e;
+        };
+        auto epi = [&](const GemmUnit& u, f32x4 acc, f32x4 extra) {
+            const int m = u.tag, nh = u.ncols, ldh = ld_heads_lds(mdl, m);
+            const int col = u.j0 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * (lane >> 4) + r, gn = n0 + row;
+                const float v = col < nh ? acc[r] + extra[0] : 0.f;
+                lds[L.heads[m] + row * ldh + col] = v;
+                if (col < nh && gn < N) buf.heads[m][(size_t)gn * nh + col] = v;
+            }
+        };
+        // W fragments of the first tile are requested before the hidden tiles
+        // have landed in LDS (S0's barrier sits inside run_units' first MFMA
+        // dependency only through LDS reads, so keep the barrier explicit)
+        run_units<true, 8>(wave, kLatentWaves, lane, get, pre, epi);
     }
     __syncthreads();
+    STAMP(buf, 2);
 
     // ---- S2: subset fusion, KL, joint latent, reparameterisation ----------
     for (int e0 = 0; e0 < kRows * D; e0 += kLatentThreads) {
@@ -343,6 +532,7 @@ __global__ __launch_bounds__(kLatentThreads) void k_latent(const KArgs a) {
             }
         }
     }
+    STAMP(buf, 10);
     // style latents and their KL
     for (int m = 0; m < M; ++m) {
         if (!((st.present_mask >> m) & 1)) continue;
@@ -372,6 +562,7 @@ __global__ __launch_bounds__(kLatentThreads) void k_latent(const KArgs a) {
             }
         }
     }
+    STAMP(buf, 11);
     // zero the K padding of every z tile (A operand of the decoder GEMM)
     for (int j = 0; j < st.num_jobs; ++j) {
         const int m = st.job_mod[j];
@@ -380,6 +571,7 @@ __global__ __launch_bounds__(kLatentThreads) void k_latent(const KArgs a) {
             lds[L.zj[j] + (e / zp) * ldzs + zd + (e % zp)] = 0.f;
     }
     __syncthreads();
+    STAMP(buf, 3);
 
     // ---- S3/S4: decoder + NLL, then d loss / d z, one pass at a time -------
     // (joint_elbo / moe: a single pass over all present modalities; poe: the
@@ -391,92 +583,142 @@ __global__ __launch_bounds__(kLatentThreads) void k_latent(const KArgs a) {
         while (je < st.num_jobs && st.job_stream[je] == st.job_stream[jb]) ++je;
         // S3: x_hat = z Wd^T + bd; Gaussian NLL epilogue (modality.py:42-45)
         {
-            int u = wave, base = 0;
-            for (int j = jb; j < je; ++j) {
-                const int m = st.job_mod[j];
-                const int dm = mdl.input_dim[m], zd = z_dim(mdl, m);
-                const int tiles = cdiv(dm, 16), ldxs = ld_x_lds(mdl, m);
-                const float* __restrict__ X = buf.x[m];
+            auto get = [&](int idx, GemmUnit& u) -> bool {
+                int base = 0;
+                for (int j = jb; j < je; ++j) {
+                    const int m = st.job_mod[j];
+                    const int dm = mdl.input_dim[m], zd = z_dim(mdl, m);
+                    const int tiles = cdiv(dm, 16);
+                    if (idx < base + tiles) {
+                        u.As = lds + L.zj[j];
+                        u.B = P + mdl.off_wd[m];
+                        u.lda = ld_z_lds(mdl, m);
+                        u.ldb = zd;
+                        u.ncols = dm;
+                        u.K = zd;
+                        u.j0 = (idx - base) * 16;
+                        u.kbeg = 0;
+                        u.kend = round_up(zd, 16);
+                        u.vec = zd % 4 == 0;
+                        u.tag = j;
+                        return true;
+                    }
+                    base += tiles;
+                }
+                return false;
+            };
+            struct DecExtra {  // what the NLL epilogue reads from global memory
+                f32x4 x;
+                float bias, lvo;
+            };
+            auto pre = [&](const GemmUnit& u) -> DecExtra {
+                const int m = st.job_mod[u.tag], dm = u.ncols;
+                const int col = u.j0 + (lane & 15);
+                const bool colv = col < dm;
+                const rsrc_t xr = make_rsrc_max(buf.x[m]);
+                DecExtra e;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    e.x[r] = ldg(xr, guard((uint32_t)(xrow[r] * dm + col) * 4u,
+                                           colv & (xrow[r] >= 0)));
+                e.bias = ldg(prsrc, guard((uint32_t)(mdl.off_bd[m] + col) * 4u, colv));
+                e.lvo = ldg(prsrc, guard((uint32_t)(mdl.off_lvo[m] + col) * 4u, colv));
+                return e;
+            };
+            auto epi = [&](const GemmUnit& u, f32x4 acc, const DecExtra& ex) {
+                const f32x4 xv = ex.x;
+                const int j = u.tag, m = st.job_mod[j], dm = u.ncols;
+                const int ldxs = ld_x_lds(mdl, m);
                 const float coef = st.job_nll_coef[j] * inv_n;
                 const size_t rbase = (size_t)st.job_slot[j] * N;
-                for (; u < base + tiles; u += kLatentWaves) {
-                    const int j0 = (u - base) * 16;
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = tile_gemm<true>(acc, lds + L.zj[j], ld_z_lds(mdl, m),
-                                          P + mdl.off_wd[m], zd, dm, zd, j0, 0,
-                                          round_up(zd, 16), lane, zd % 4 == 0);
-                    const int col = j0 + (lane & 15);
-                    const bool colv = col < dm;
-                    const float bias = colv ? P[mdl.off_bd[m] + col] : 0.f;
-                    const float lvo = colv ? P[mdl.off_lvo[m] + col] : 0.f;
-                    const float inv_var = expf(-lvo);
-                    float nll = 0.f, glv = 0.f;
+                const int col = u.j0 + (lane & 15);
+                const bool colv = col < dm;
+                const float bias = ex.bias, lvo = ex.lvo;
+                const float inv_var = expf(-lvo);
+                float nll = 0.f, glv = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 4 * (lane >> 4) + r, gn = n0 + row;
-                        const bool valid = colv && gn < N;
-                        float g = 0.f;
-                        if (valid) {
-                            const float xhat = acc[r] + bias;
-                            const float x = X[(size_t)src_row(buf, gn) * dm + col];
-                            const float diff = x - xhat;
-                            const float q = 0.5f * diff * diff * inv_var;
-                            nll += q + 0.5f * lvo + kHalfLog2Pi;
-                            glv += 0.5f - q;
-                            g = -diff * inv_var * coef;
-                            buf.loc[m][(rbase + gn) * dm + col] = xhat;
-                            if (bwd) buf.g_xhat[m][(rbase + gn) * dm + col] = g;
-                        }
-                        if (bwd) lds[L.gx[m] + row * ldxs + col] = g;
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * (lane >> 4) + r, gn = n0 + row;
+                    const bool valid = colv && gn < N;
+                    float g = 0.f;
+                    if (valid) {
+                        const float xhat = acc[r] + bias;
+                        const float diff = xv[r] - xhat;
+                        const float q = 0.5f * diff * diff * inv_var;
+                        nll += q + 0.5f * lvo + kHalfLog2Pi;
+                        glv += 0.5f - q;
+                        g = -diff * inv_var * coef;
+                        buf.loc[m][(rbase + gn) * dm + col] = xhat;
+                        if (bwd) buf.g_xhat[m][(rbase + gn) * dm + col] = g;
                     }
-                    const float ws = wave_sum(nll);
-                    if (lane == 0) red[wave * kStatStride + kPartNll + j] += ws;
-                    if (bwd) {
-                        glv += __shfl_xor(glv, 16, kWave);
-                        glv += __shfl_xor(glv, 32, kWave);
-                        if (lane < 16 && colv) {
-                            float* p = part + lvo_part_off(mdl, m) + col;
-                            const float v = glv * coef;
-                            *p = (st.job_slot[j] == 0) ? v : *p + v;
-                        }
-                    }
+                    if (bwd) lds[L.gx[m] + row * ldxs + col] = g;
                 }
-                base += tiles;
-            }
+                const float ws = wave_sum(nll);
+                if (lane == 0) red[wave * kStatStride + kPartNll + j] += ws;
+                if (bwd) {
+                    glv += __shfl_xor(glv, 16, kWave);
+                    glv += __shfl_xor(glv, 32, kWave);
+                    if (lane < 16 && colv)
+                        part[lvo_part_off(mdl, m) + st.job_slot[j] * lvo_slot_stride(mdl, m) +
+                             col] = glv * coef;
+                }
+            };
+            run_units<true, 4>(wave, kLatentWaves, lane, get, pre, epi);
         }
+        STAMP(buf, 12);
         if (!bwd) {
             jb = je;
             continue;
         }
         __syncthreads();
+        STAMP(buf, 4);
         // S4: g_z = g_xhat Wd, K = d_m split in kGzChunks partial slabs
         {
-            int u = wave, base = 0, zoff = 0;
-            for (int j = jb; j < je; ++j) {
-                const int m = st.job_mod[j];
-                const int dm = mdl.input_dim[m], zd = z_dim(mdl, m);
-                const int ct = cdiv(zd, 16), Kp = round_up(dm, 16);
-                const int kch = round_up(cdiv(Kp, kGzChunks), 16);
-                const int units = ct * kGzChunks;
-                for (; u < base + units; u += kLatentWaves) {
-                    const int t = (u - base) / kGzChunks, c = (u - base) % kGzChunks;
-                    const int kbeg = min(c * kch, Kp), kend = min(kbeg + kch, Kp);
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = tile_gemm<false>(acc, lds + L.gx[m], ld_x_lds(mdl, m),
-                                           P + mdl.off_wd[m], zd, zd, dm, t * 16, kbeg,
-                                           kend, lane, false);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 4 * (lane >> 4) + r;
-                        lds[L.gzp + (c * kRows + row) * L.ld_gzp + zoff + t * 16 +
-                            (lane & 15)] = acc[r];
+            auto get = [&](int idx, GemmUnit& u) -> bool {
+                int base = 0, zoff = 0;
+                for (int j = jb; j < je; ++j) {
+                    const int m = st.job_mod[j];
+                    const int dm = mdl.input_dim[m], zd = z_dim(mdl, m);
+                    const int ct = cdiv(zd, 16), Kp = round_up(dm, 16);
+                    const int kch = round_up(cdiv(Kp, kGzChunks), 16);
+                    const int units = ct * kGzChunks;
+                    if (idx < base + units) {
+                        const int t = (idx - base) / kGzChunks, c = (idx - base) % kGzChunks;
+                        u.As = lds + L.gx[m];
+                        u.B = P + mdl.off_wd[m];
+                        u.lda = ld_x_lds(mdl, m);
+                        u.ldb = zd;
+                        u.ncols = zd;
+                        u.K = dm;
+                        u.j0 = t * 16;
+                        u.kbeg = min(c * kch, Kp);
+                        u.kend = min(u.kbeg + kch, Kp);
+                        u.vec = 0;
+                        u.tag = c;
+                        u.tag2 = zoff + t * 16;
+                        return true;
                     }
+                    base += units;
+                    zoff += round_up(zd, 16);
                 }
-                base += units;
-                zoff += round_up(zd, 16);
-            }
+                return false;
+            };
+            auto pre = [&](const GemmUnit&) -> f32x4 {
+                const f32x4 e = {0.f, 0.f, 0.f, 0.f};
+                return e;
+            };
+            auto epi = [&](const GemmUnit& u, f32x4 acc, f32x4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * (lane >> 4) + r;
+                    lds[L.gzp + (u.tag * kRows + row) * L.ld_gzp + u.tag2 + (lane & 15)] =
+                        acc[r];
+                }
+            };
+            run_units<false, 8>(wave, kLatentWaves, lane, get, pre, epi);
         }
         __syncthreads();
+        STAMP(buf, 5);
         {
             int zoff = 0;
             for (int j = jb; j < je; ++j) {
@@ -497,6 +739,7 @@ __global__ __launch_bounds__(kLatentThreads) void k_latent(const KArgs a) {
         jb = je;
     }
 
+    STAMP(buf, 6);
     if (bwd) {
         // ---- S5: backward of reparameterisation, KL and subset fusion ------
         for (int e0 = 0; e0 < kRows * D; e0 += kLatentThreads) {
@@ -613,41 +856,70 @@ __global__ __launch_bounds__(kLatentThreads) void k_latent(const KArgs a) {
                 lds[L.gheads[m] + (e / pad) * ldh + nh + (e % pad)] = 0.f;
         }
         __syncthreads();
+        STAMP(buf, 7);
 
         // ---- S6: g_pre = (g_heads Wh) * [h > 0] ---------------------------
         {
-            int u = wave, base = 0;
-            for (int m = 0; m < M; ++m) {
-                if (!((st.present_mask >> m) & 1)) continue;
-                const int nh = heads_dim(mdl, m);
-                const float* __restrict__ H = buf.hidden[m];
-                for (; u < base + kHid / 16; u += kLatentWaves) {
-                    const int j0 = (u - base) * 16;
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = tile_gemm<false>(acc, lds + L.gheads[m], ld_heads_lds(mdl, m),
-                                           P + mdl.off_wh[m], kHid, kHid, nh, j0, 0,
-                                           round_up(nh, 16), lane, false);
-                    const int col = j0 + (lane & 15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int gn = n0 + 4 * (lane >> 4) + r;
-                        if (gn < N) {
-                            const float h = H[(size_t)gn * kHid + col];
-                            buf.g_pre[m][(size_t)gn * kHid + col] = h > 0.f ? acc[r] : 0.f;
-                        }
+            auto get = [&](int idx, GemmUnit& u) -> bool {
+                int base = 0;
+                for (int m = 0; m < M; ++m) {
+                    if (!((st.present_mask >> m) & 1)) continue;
+                    if (idx < base + kHid / 16) {
+                        const int nh = heads_dim(mdl, m);
+                        u.As = lds + L.gheads[m];
+                        u.B = P + mdl.off_wh[m];
+                        u.lda = ld_heads_lds(mdl, m);
+                        u.ldb = kHid;
+                        u.ncols = kHid;
+                        u.K = nh;
+                        u.j0 = (idx - base) * 16;
+                        u.kbeg = 0;
+                        u.kend = round_up(nh, 16);
+                        u.vec = 0;
+                        u.tag = m;
+                        return true;
                     }
+                    base += kHid / 16;
                 }
-                base += kHid / 16;
-            }
+                return false;
+            };
+            auto pre = [&](const GemmUnit& u) -> f32x4 {  // h, for the ReLU mask
+                const int col = u.j0 + (lane & 15);
+                const rsrc_t hr = make_rsrc(buf.hidden[u.tag], (size_t)N * kHid * sizeof(float));
+                f32x4 e;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)   // rows >= N are out of range
+                    e[r] = ldg(hr, (uint32_t)((n0 + 4 * (lane >> 4) + r) * kHid + col) * 4u);
+                return e;
+            };
+            auto epi = [&](const GemmUnit& u, f32x4 acc, f32x4 h) {
+                const int col = u.j0 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gn = n0 + 4 * (lane >> 4) + r;
+                    if (gn < N)
+                        buf.g_pre[u.tag][(size_t)gn * kHid + col] = h[r] > 0.f ? acc[r] : 0.f;
+                }
+            };
+#ifdef MOPOE_STAMPS
+            unsigned long long* usp =
+                (blockIdx.x == 0 && tid == 0)
+                    ? reinterpret_cast<unsigned long long*>(buf.stats + 64) + 32 : nullptr;
+            run_units<false, 6>(wave, kLatentWaves, lane, get, pre, epi, usp);
+#else
+            run_units<false, 6>(wave, kLatentWaves, lane, get, pre, epi);
+#endif
         }
     }
     __syncthreads();
+    STAMP(buf, 8);
     if (tid < kNumPart) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < kLatentWaves; ++w) s += red[w * kStatStride + tid];
         part[tid] = s;
     }
+    STAMP(buf, 9);
 }
 
 // Scalars of the step from the row tiles' partial sums, in a fixed order
@@ -729,44 +1001,58 @@ struct WArgs {
     mopoe_adam adam;
 };
 
-struct AdamCoef {
-    float b1, b2, one_m_b1, one_m_b2, step_size, bc2_sqrt, eps;
-};
-
-DEV AdamCoef adam_coef(const mopoe_adam& ad, int t) {
-    // torch.optim.Adam (_single_tensor_adam): python-double scalars applied
-    // to float32 tensors
-    AdamCoef c;
-    const double b1 = (double)ad.beta1, b2 = (double)ad.beta2;
-    const double bc1 = 1.0 - pow(b1, (double)t);
-    const double bc2 = 1.0 - pow(b2, (double)t);
-    c.b1 = ad.beta1;
-    c.b2 = ad.beta2;
-    c.one_m_b1 = (float)(1.0 - b1);
-    c.one_m_b2 = (float)(1.0 - b2);
-    c.step_size = (float)((double)ad.lr / bc1);
-    c.bc2_sqrt = (float)sqrt(bc2);
-    c.eps = ad.eps;
-    return c;
-}
-
-DEV void adam_update(const AdamCoef& c, float g, float* p, float* m, float* v) {
-    const float m1 = *m + c.one_m_b1 * (g - *m);           // exp_avg.lerp_(g, 1-b1)
-    const float v1 = *v * c.b2 + (c.one_m_b2 * g) * g;     // mul_(b2).addcmul_(g, g, 1-b2)
-    const float denom = sqrtf(v1) / c.bc2_sqrt + c.eps;
-    *m = m1;
-    *v = v1;
-    *p = *p - c.step_size * (m1 / denom);                  // addcdiv_(m, denom, -step)
+// One wave's share of a G^T X tile: rows [rbeg, rend) in rounds of 64, i.e. 16
+// G + 16 X values per lane in flight per round, all from clamped addresses
+// (no conditional loads) and masked afterwards.
+template <bool GATHER>
+DEV f32x4 wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int ldg_, int ldx,
+                     int ci, int cj, int rbeg, int rend, int q, bool iv, bool jv, bool jb) {
+    const float bfill = jb ? 1.f : 0.f;
+    auto load = [&](int rb, float (&av)[16], float (&bv)[16]) {
+        int xrow[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int r = rb + 4 * s + q;
+            xrow[s] = GATHER ? xrows[min(r, rend - 1)] : r;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int r = rb + 4 * s + q;
+            const bool rv = r < rend;
+            av[s] = ldg(gr, guard((uint32_t)(r * ldg_ + ci) * 4u, rv & iv));
+            const float x = ldg(xr, guard((uint32_t)(xrow[s] * ldx + cj) * 4u, rv & jv));
+            bv[s] = x + (rv ? bfill : 0.f);  // x is 0 unless jv (hardware range check)
+        }
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    float av[16], bv[16];
+    load(rbeg, av, bv);
+    for (int rb = rbeg; rb < rend; rb += 64) {
+        float an[16], bn[16];
+        load(rb + 64, an, bn);  // all out of range (zeros) past rend
+#pragma unroll
+        for (int s = 0; s < 16; s += 2) {
+            acc = mfma_16x16x4(av[s], bv[s], acc);
+            acc2 = mfma_16x16x4(av[s + 1], bv[s + 1], acc2);
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            av[s] = an[s];
+            bv[s] = bn[s];
+        }
+    }
+    return acc + acc2;
 }
 
 __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
     __shared__ f32x4 redacc[4][kWave];
     const mopoe_buffers& buf = a.buf;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave id as a provably wave-uniform scalar (guide T20): everything derived
+    // from it stays in SGPRs and buffer descriptors need no waterfall loop
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     const bool fuse = w.fuse_adam != 0;
-    AdamCoef ac;
-    if (fuse) ac = adam_coef(w.adam, buf.counters[0]);
 
     if (b < w.total_tiles) {
         int ji = 0;
@@ -780,30 +1066,42 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
         const int ci = i0 + (lane & 15), cj = j0 + (lane & 15), q = lane >> 4;
         const bool iv = ci < job.gcols;
         const bool jv = cj < job.xcols, jb = cj == job.xcols;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-        for (int rb = rbeg; rb < rend; rb += 16) {
-            float av[4], bv[4];
+
+        // wave 0 owns the epilogue: its parameter / moment values are
+        // requested first so the Adam update does not wait on them later
+        int idx[4];
+        float pp[4], pm[4], pv[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int r = rb + 4 * s + q;
-                const bool rv = r < rend;
-                av[s] = (rv && iv) ? job.G[(size_t)r * job.ldg + ci] : 0.f;
-                float x = 0.f;
-                if (rv) {
-                    if (jv) {
-                        const int xr = job.xrows ? job.xrows[r] : r;
-                        x = job.X[(size_t)xr * job.ldx + cj];
-                    } else if (jb) {
-                        x = 1.f;
-                    }
-                }
-                bv[s] = x;
-            }
-            acc = mfma_16x16x4(av[0], bv[0], acc);
-            acc2 = mfma_16x16x4(av[1], bv[1], acc2);
-            acc = mfma_16x16x4(av[2], bv[2], acc);
-            acc2 = mfma_16x16x4(av[3], bv[3], acc2);
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 4 * q + r;
+            const int iw = job.off_w + i * job.xcols + cj;
+            const int ib = job.off_b + i;
+            int id = jv ? iw : ((jb && job.off_b >= 0) ? ib : -1);
+            idx[r] = i < job.gcols ? id : -1;
+            pp[r] = pm[r] = pv[r] = 0.f;
         }
+        if (fuse && wave == 0) {
+            const size_t pbytes = (size_t)a.mdl.num_floats * sizeof(float);
+            const rsrc_t rp = make_rsrc(buf.params, pbytes);
+            const rsrc_t rm = make_rsrc(buf.exp_avg, pbytes);
+            const rsrc_t rv = make_rsrc(buf.exp_avg_sq, pbytes);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t o = guard((uint32_t)idx[r] * 4u, idx[r] >= 0);
+                pp[r] = ldg(rp, o);
+                pm[r] = ldg(rm, o);
+                pv[r] = ldg(rv, o);
+            }
+        }
+
+        const rsrc_t gr = make_rsrc(job.G, (size_t)R * job.ldg * sizeof(float));
+        const rsrc_t xr = make_rsrc_max(job.X);
+        const f32x4 acc =
+            job.xrows ? wgrad_rows<true>(gr, xr, job.xrows, job.ldg, job.ldx, ci, cj, rbeg,
+                                         rend, q, iv, jv, jb)
+                      : wgrad_rows<false>(gr, xr, nullptr, job.ldg, job.ldx, ci, cj, rbeg,
+                                          rend, q, iv, jv, jb);
+        const f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
         redacc[wave][lane] = acc + acc2;
         __syncthreads();
         if (wave == 0) {
@@ -811,24 +1109,21 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
             g += redacc[1][lane];
             g += redacc[2][lane];
             g += redacc[3][lane];
+            AdamCoef ac;
+            if (fuse) ac = adam_coef_load(buf.counters, w.adam);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = i0 + 4 * q + r;
-                if (i >= job.gcols) continue;
-                int idx = -1;
-                if (jv)
-                    idx = job.off_w + i * job.xcols + cj;
-                else if (jb && job.off_b >= 0)
-                    idx = job.off_b + i;
-                if (idx < 0) continue;
-                buf.grads[idx] = g[r];
+                if (idx[r] < 0) continue;
+                buf.grads[idx[r]] = g[r];
                 if (fuse)
-                    adam_update(ac, g[r], buf.params + idx, buf.exp_avg + idx,
-                                buf.exp_avg_sq + idx);
+                    adam_update(ac, g[r], pp[r], pm[r], pv[r], buf.params + idx[r],
+                                buf.exp_avg + idx[r], buf.exp_avg_sq + idx[r]);
             }
         }
         return;
     }
+    AdamCoef ac;
+    if (fuse) ac = adam_coef_load(buf.counters, w.adam);
     const int lb = b - w.total_tiles;
     if (lb < w.lvo_blocks) {
         const int tiles = cdiv(a.st.n, kRows);
@@ -839,13 +1134,19 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
         const int col = (lb - w.lvo_block_begin[m]) * 256 + tid;
         if (col < a.mdl.input_dim[m]) {
             float g = 0.f;
-            const float* p = buf.partials + lvo_part_off(a.mdl, m) + col;
-            for (int t = 0; t < tiles; ++t) g += p[(size_t)t * stride];
+            int slots = 0;
+            for (int j = 0; j < a.st.num_jobs; ++j) slots += a.st.job_mod[j] == m;
+            for (int sl = 0; sl < slots; ++sl) {
+                const float* p = buf.partials + lvo_part_off(a.mdl, m) +
+                                 sl * lvo_slot_stride(a.mdl, m) + col;
+                for (int t = 0; t < tiles; ++t) g += p[(size_t)t * stride];
+            }
             const int idx = a.mdl.off_lvo[m] + col;
             if (a.mdl.learn_output_scale) {
                 buf.grads[idx] = g;
                 if (fuse)
-                    adam_update(ac, g, buf.params + idx, buf.exp_avg + idx,
+                    adam_update(ac, g, buf.params[idx], buf.exp_avg[idx],
+                                buf.exp_avg_sq[idx], buf.params + idx, buf.exp_avg + idx,
                                 buf.exp_avg_sq + idx);
             } else {
                 buf.grads[idx] = 0.f;
@@ -876,12 +1177,16 @@ struct AdamSegs {
 };
 
 __global__ __launch_bounds__(256) void k_adam(const mopoe_buffers buf, const AdamSegs s) {
-    const AdamCoef ac = adam_coef(s.adam, buf.counters[0]);
+    __shared__ AdamCoef sc;
+    if (threadIdx.x == 0) sc = adam_coef_load(buf.counters, s.adam);
+    __syncthreads();
+    const AdamCoef ac = sc;
     const int beg = s.begin[blockIdx.y], end = s.end[blockIdx.y];
     for (int i = beg + blockIdx.x * blockDim.x + threadIdx.x; i < end;
          i += gridDim.x * blockDim.x) {
         const float g = buf.grads[i] * s.grad_scale;
-        adam_update(ac, g, buf.params + i, buf.exp_avg + i, buf.exp_avg_sq + i);
+        adam_update(ac, g, buf.params[i], buf.exp_avg[i], buf.exp_avg_sq[i], buf.params + i,
+                    buf.exp_avg + i, buf.exp_avg_sq + i);
     }
 }
 
@@ -1104,13 +1409,15 @@ int launch_linear(const LinArgs& la, int max_k, int max_cols, hipStream_t s) {
     return check_launch("k_linear");
 }
 
-int launch_forward_part(const KArgs& ka, hipStream_t s) {
+int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) {
     const mopoe_model& mdl = ka.mdl;
     const int tiles = cdiv(ka.st.n, kRows);
     LinArgs la;
     memset(&la, 0, sizeof(la));
     la.n = ka.st.n;
-    la.bump = ka.st.backward ? ka.buf.counters : nullptr;
+    la.counters = ka.st.backward ? ka.buf.counters : nullptr;
+    la.publish = adam != nullptr;
+    if (adam) la.adam = *adam;
     int maxd = 1;
     for (int m = 0; m < mdl.num_mods; ++m) {
         if (!((ka.st.present_mask >> m) & 1)) continue;
@@ -1142,7 +1449,10 @@ int launch_forward_part(const KArgs& ka, hipStream_t s) {
     }
     {
         ProfScope ps(MOPOE_KERNEL_LATENT, s);
-        hipLaunchKernelGGL(k_latent, dim3(tiles), dim3(kLatentThreads), (size_t)lds, s, ka);
+        // + L2 warmers on the CUs the row tiles leave idle (see k_latent)
+        const int warm = tiles < 128 ? 128 : 0;
+        hipLaunchKernelGGL(k_latent, dim3(tiles + warm), dim3(kLatentThreads), (size_t)lds, s,
+                           ka);
     }
     return check_launch("k_latent");
 }
@@ -1276,7 +1586,7 @@ int mopoe_forward(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buff
     ka.st.backward = 0;
     latent_lds_layout(ka.mdl, ka.st, kLatentWaves, ka.lds);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (int rc = launch_forward_part(ka, s)) return rc;
+    if (int rc = launch_forward_part(ka, nullptr, s)) return rc;
     {
         ProfScope ps(MOPOE_KERNEL_FINALIZE, s);
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, ka);
@@ -1297,7 +1607,7 @@ int mopoe_train_step(const mopoe_model* mdl, const mopoe_step* st, const mopoe_b
     ka.st.sample = 1;
     latent_lds_layout(ka.mdl, ka.st, kLatentWaves, ka.lds);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (int rc = launch_forward_part(ka, s)) return rc;
+    if (int rc = launch_forward_part(ka, adam, s)) return rc;
     WArgs w;
     build_wargs(ka, adam, w);
     {

@@ -32,7 +32,8 @@ class Workspace:
         self.z = [torch.zeros(slots * n, spec.ldz(m), **f) for m in range(M)]
         self.loc = [torch.empty(slots * n, spec.input_dim[m], **f)
                     for m in range(M)]
-        self.stats = torch.zeros(L.NUM_STATS, **f)
+        self._stats_all = torch.zeros(64 + 128, **f)   # [64:] diagnostic stamps
+        self.stats = self._stats_all[:L.NUM_STATS]
         tiles = (n + L.ROWS - 1) // L.ROWS
         stride = L.lib.mopoe_partials_stride(spec.c_model)
         self.partials = torch.zeros(tiles, stride, **f)
@@ -58,7 +59,7 @@ class MoPoEEngine:
         self.grads = torch.zeros(P, **f)
         self.exp_avg = torch.zeros(P, **f)
         self.exp_avg_sq = torch.zeros(P, **f)
-        self.counters = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.counters = torch.zeros(16, dtype=torch.int32, device=self.device)
         self.views = spec.param_views(self.params)
         self.grad_views = spec.param_views(self.grads)
         self.seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1)

@@ -153,7 +153,8 @@ typedef struct mopoe_buffers {
     float* grads;                        /* (num_floats)  written by backward  */
     float* exp_avg;                      /* (num_floats)  Adam m               */
     float* exp_avg_sq;                   /* (num_floats)  Adam v               */
-    int32_t* counters;                   /* [0] steps begun, [1] steps done    */
+    int32_t* counters;                   /* (16) [0] steps begun, [1] steps done,
+                                            [3..10] Adam coefficients of step [0] */
 
     const float* x[MOPOE_MAX_MODS];      /* (rows, d_m) input, ld = d_m        */
     const int32_t* row_index;            /* optional (n): x row of batch row   */
