@@ -1,0 +1,135 @@
+"""Mirror of the reference's run_epochs.py: basic_routine_epoch / train /
+test / run_epochs with the reference's signatures and return values, the hot
+loop running on the HIP engine.
+
+`basic_routine_epoch` under torch.no_grad() (test) runs the fused forward and
+returns the loss terms; with grad enabled it runs the fused forward+backward
+(gradients land in the model's flat gradient buffer) and returns a
+`total_loss` whose `.backward()` publishes them as `param.grad`, so that the
+reference's `optimizer.zero_grad(); total_loss.backward(); optimizer.step()`
+sequence (run_epochs.py:180-182) is unchanged.
+"""
+import os
+
+import torch
+from torch.utils.data import DataLoader
+
+from . import _lib as L
+
+
+class _FusedLoss(torch.autograd.Function):
+    """total_loss of a step whose gradients already sit in engine.grads."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, loss_view):
+        ctx.model = model
+        return loss_view.detach().clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model = ctx.model
+        eng = model.engine
+        mask = eng.last_present_mask
+        names = eng.spec.names
+        for name, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            m = names.index(name.split(".")[1])
+            if not (mask >> m) & 1:
+                continue          # absent modality: .grad stays None (as in torch)
+            g = eng.grad_views[name]
+            p.grad = g if p.grad is None or p.grad.data_ptr() == g.data_ptr() else p.grad + g
+        return None, None, None
+
+
+def basic_routine_epoch(exp, model_idx, batch):
+    """reference run_epochs.py:73-135"""
+    model = exp.models
+    if exp.flags.num_models > 1:
+        model = model[model_idx]
+    batch_d = batch[0]
+    for m_key in batch_d.keys():                     # run_epochs.py:85-86
+        batch_d[m_key] = batch_d[m_key].to(exp.flags.device).float()
+    eng = model.engine
+    if torch.is_grad_enabled():
+        plan, ws = eng.train_step(batch_d, apply_adam=False)
+        sc = eng.scalars(plan, ws)
+        total_loss = _FusedLoss.apply(model._anchor, model, sc["total_loss"])
+    else:
+        plan, ws = eng.forward(batch_d, sample=True, loss=True, fresh=True)
+        sc = eng.scalars(plan, ws)
+        total_loss = sc["total_loss"]
+    return {"results": eng.results(plan, ws), "log_probs": sc["log_probs"],
+            "total_loss": total_loss, "klds": sc["klds"]}
+
+
+def train(model_idx, epoch, exp, tb_logger):
+    """reference run_epochs.py:138-184"""
+    model, dataset, optimizer = exp.models, exp.dataset_train, exp.optimizers
+    if exp.flags.num_models > 1:
+        model, dataset, optimizer = model[model_idx], dataset[model_idx], optimizer[model_idx]
+    model.train()
+    for batch in _loader(exp, dataset, train=True):
+        basic_routine = basic_routine_epoch(exp, model_idx, batch)
+        if getattr(exp.flags, "grad_scaling", False):
+            raise NotImplementedError("grad_scaling (the reference's branch never calls "
+                                      "zero_grad, SURVEY.md appendix C)")
+        optimizer.zero_grad()
+        basic_routine["total_loss"].backward()
+        optimizer.step()
+        if tb_logger is not None:
+            tb_logger.write_training_logs(basic_routine["results"],
+                                          basic_routine["total_loss"],
+                                          basic_routine["log_probs"], basic_routine["klds"])
+
+
+def test(model_idx, epoch, exp, tb_logger):
+    """reference run_epochs.py:187-219 (latents are still sampled)."""
+    with torch.no_grad():
+        model, dataset = exp.models, exp.dataset_test
+        if exp.flags.num_models > 1:
+            model, dataset = model[model_idx], dataset[model_idx]
+        model.eval()
+        for batch in _loader(exp, dataset, train=False):
+            basic_routine = basic_routine_epoch(exp, model_idx, batch)
+            if tb_logger is not None:
+                tb_logger.write_testing_logs(basic_routine["results"],
+                                             basic_routine["total_loss"],
+                                             basic_routine["log_probs"],
+                                             basic_routine["klds"])
+
+
+def _loader(exp, dataset, train):
+    """The reference builds DataLoader(dataset, batch_sampler=
+    MissingModalitySampler(...), num_workers=8) for training and a plain
+    batched DataLoader for testing (run_epochs.py:155-157,201)."""
+    if hasattr(dataset, "__iter__") and not hasattr(dataset, "__getitem__"):
+        return dataset                      # an iterable of ready batches
+    sampler_cls = getattr(exp, "batch_sampler_cls", None)
+    workers = getattr(exp.flags, "num_workers", 0)
+    if train and sampler_cls is not None:
+        return DataLoader(dataset, batch_sampler=sampler_cls(
+            dataset, batch_size=exp.flags.batch_size), num_workers=workers)
+    return DataLoader(dataset, batch_size=exp.flags.batch_size, num_workers=workers)
+
+
+def run_epochs(exp, tb_logger=None):
+    """reference run_epochs.py:222-256: epochs of train + test, checkpoints
+    every 5 epochs under <dir_checkpoints>/<epoch:04d>/<model_save>."""
+    for model_idx in range(exp.flags.num_models):
+        for epoch in range(exp.flags.start_epoch, exp.flags.end_epoch):
+            train(model_idx, epoch, exp, tb_logger)
+            test(model_idx, epoch, exp, tb_logger)
+            if (epoch + 1) % 5 == 0 or (epoch + 1) == exp.flags.end_epoch:
+                model = exp.models
+                dir_network_epoch = os.path.join(exp.flags.dir_checkpoints,
+                                                 str(epoch).zfill(4))
+                if exp.flags.num_models > 1:
+                    model = model[model_idx]
+                    dir_network_epoch = os.path.join(
+                        exp.flags.dir_checkpoints, "model_%d" % model_idx,
+                        str(epoch).zfill(4))
+                os.makedirs(dir_network_epoch, exist_ok=True)
+                model.save_networks()
+                torch.save(model.state_dict(),
+                           os.path.join(dir_network_epoch, exp.flags.model_save))

@@ -1,0 +1,122 @@
+"""CPU: the host side of the boundary -- the C ABI loads and exports what
+include/mopoe_hip.h declares, descriptors are validated before any HIP call,
+the mirror modules keep the reference's state_dict keys, and the per-batch
+plan reproduces the reference's float32 slice arithmetic."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import mopoe_amd as mm
+import mopoe_oracle as mo
+from golden_util import Fixture, case_names
+from surface_util import make_experiment
+
+L = mm._lib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mopoe_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(mopoe_[a-z0-9_]+)\s*\(", header, re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    for name in declared:
+        assert getattr(L.lib, name) is not None
+    assert L.lib.mopoe_abi_version() == L.ABI_VERSION
+
+
+def test_struct_mirrors_match_the_c_layout():
+    sizes = [C.sizeof(L.Model), C.sizeof(L.Step), C.sizeof(L.Buffers), C.sizeof(L.Adam)]
+    assert [L.lib.mopoe_sizeof(i) for i in range(4)] == sizes
+    assert L.lib.mopoe_sizeof(99) == -1
+
+
+def test_descriptors_are_rejected_before_any_gpu_work():
+    spec = mm.ModelSpec(["clinical", "rois"], [7, 444], [3, 20])
+    plan = spec.plan(["clinical", "rois"], 32, backward=True)
+    buf = L.Buffers()                       # all NULL
+    rc = L.lib.mopoe_train_step(spec.c_model, plan.c_step, buf, None, None)
+    assert rc == -1 and b"null" in L.lib.mopoe_last_error()
+    bad = L.Step.from_buffer_copy(plan.c_step)
+    bad.present_mask = 0
+    assert L.lib.mopoe_forward(spec.c_model, bad, buf, None) == -1
+    assert b"present_mask" in L.lib.mopoe_last_error()
+    with pytest.raises(L.MopoeError):
+        L.check(-1, "x")
+    assert L.lib.mopoe_poe(None, None, 1, 1, 1e-8, None, None, None) == -1
+
+
+def test_no_cpu_fallback():
+    spec = mm.ModelSpec(["clinical", "rois"], [7, 444], [3, 20])
+    eng = mm.MoPoEEngine(spec, "cpu")
+    x = mo.make_inputs(spec.names, spec.input_dim, 8, seed=0)
+    if not torch.cuda.is_available():
+        with pytest.raises(L.MopoeError):
+            eng.train_step(x)
+        with pytest.raises(L.MopoeError):
+            eng.forward(x)
+
+
+def test_flat_layout_covers_every_reference_parameter():
+    for names, dims, style, fact in ((["clinical", "rois"], [7, 444], [3, 20], True),
+                                     (["a", "b", "c", "d"], [7, 444, 128, 64], [3, 20], True),
+                                     (["clinical", "rois"], [7, 444], [3, 20], False)):
+        cfg = mo.Config(names, dims, style, factorized=fact)
+        spec = mm.ModelSpec(names, dims, style, factorized=fact)
+        flat = torch.arange(spec.num_floats, dtype=torch.float32)
+        views = spec.param_views(flat)
+        shapes = mo.param_shapes(cfg)
+        assert set(views) == set(shapes)
+        seen = torch.zeros(spec.num_floats, dtype=torch.int32)
+        for k, v in views.items():
+            assert tuple(v.shape) == tuple(shapes[k]), k
+            seen[v.reshape(-1).long()] += 1
+        assert int(seen.max()) == 1                      # no overlap
+        assert int(seen.sum()) == sum(v.numel() for v in views.values())
+        c = spec.c_model
+        for m in range(len(names)):                      # 64-float alignment
+            for off in (c.off_w1[m], c.off_b1[m], c.off_wh[m], c.off_bh[m],
+                        c.off_wd[m], c.off_bd[m], c.off_lvo[m]):
+                assert off % 64 == 0
+
+
+@pytest.mark.parametrize("method", ["joint_elbo", "poe", "moe"])
+def test_model_keeps_reference_state_dict_keys(method):
+    cfg = mo.Config(["clinical", "rois"], [7, 444], [3, 20], method=method)
+    exp = make_experiment(cfg, "cpu")
+    model = exp.models
+    init = mo.init_params(cfg, 0)
+    assert set(model.state_dict().keys()) == set(init.keys())
+    missing, unexpected = model.load_state_dict(init, strict=True)
+    assert not missing and not unexpected
+    base = model.engine.params
+    for k, p in model.named_parameters():
+        assert torch.equal(p.detach(), init[k]), k
+        assert base.data_ptr() <= p.data_ptr() < base.data_ptr() + 4 * base.numel()
+    assert [k for k, p in model.named_parameters() if not p.requires_grad] == []
+    assert list(exp.subsets.keys()) == ["", "clinical", "rois", "clinical_rois"]
+
+
+@pytest.mark.parametrize("case", case_names())
+def test_plan_reproduces_reference_mixture_and_subsets(case):
+    fx = Fixture(case)
+    cfg = fx.cfg
+    spec = mm.ModelSpec(cfg.names, cfg.input_dim, cfg.style_dim, method=cfg.method,
+                        factorized=cfg.factorized)
+    plan = spec.plan(fx.present, fx.N, backward=True)
+    # subset keys / availability as the reference recorded them
+    want = [k.split("/")[2] for k in fx.keys("step0/klds/")]
+    assert plan.avail_keys == want
+    K = len(fx.z["step0/weights"])
+    assert plan.c_step.num_comp == K
+    w = mo.reweight_weights((1 / float(K)) * torch.ones(K))
+    starts, ends = mo.mixture_bounds(fx.N, w)
+    f = plan.c_step.comp_f
+    for n in range(fx.N):
+        k = min(n // f, K - 1) if f > 0 else K - 1
+        assert starts[k] <= n < ends[k]
+    assert abs(sum(plan.comp_w) - 1.0) < 1e-6
+    assert plan.lds_bytes() <= 160 * 1024
