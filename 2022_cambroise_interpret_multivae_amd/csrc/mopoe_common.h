@@ -49,58 +49,95 @@ HD int lvo_slot_stride(const mopoe_model& m, int i) { return round_up(m.input_di
 HD int partials_stride(const mopoe_model& m) { return lvo_part_off(m, m.num_mods); }
 
 // ---------------------------------------------------------------------------
-// LDS carve-up of the fused latent kernel (floats).  Region R0 holds the
-// hidden tiles while the heads GEMM runs and is re-used afterwards for the
-// decoder-gradient tiles (g_xhat) and the K-split partials of g_z.
+// LDS carve-up of the fused latent kernel (floats), computed on the host and
+// handed over in the kernel arguments.  Region R0 is time-shared: the hidden
+// tiles (heads GEMM), then the input tiles x (NLL epilogue; turned into g_xhat
+// in place when the modality is decoded once) + the K-split partials of g_z;
+// the per-element KL terms overlay the partials' area until they are reduced.
 // ---------------------------------------------------------------------------
 struct LatentLds {
-    int hs[MOPOE_MAX_MODS];
-    int gx[MOPOE_MAX_MODS];
-    int gzp;      // [kGzChunks][kRows][ld_gzp]
-    int ld_gzp;
-    int heads[MOPOE_MAX_MODS];
-    int gheads[MOPOE_MAX_MODS];
-    int zj[MOPOE_MAX_JOBS];
-    int gzj[MOPOE_MAX_JOBS];
-    int red;      // [waves][kStatStride]
+    int hs[MOPOE_MAX_MODS];      // R0: hidden tile            [16][kLdH]
+    int xs[MOPOE_MAX_MODS];      // R0: input tile             [16][ld_x]
+    int gx[MOPOE_MAX_MODS];      // g_xhat tile (= xs when decoded once)
+    int gzp, ld_gzp, gz_chunks;  // R0: g_z partials           [chunks][16][ld_gzp]
+    int klt;                     // overlays gzp: KL terms     [subsets][16*D], then styles
+    int klt_style[MOPOE_MAX_MODS];
+    int heads[MOPOE_MAX_MODS];   // encoder outputs            [16][ld_heads]
+    int gheads[MOPOE_MAX_MODS];  // their gradient (second K-half partial during S1)
+    int tm[MOPOE_MAX_MODS];      // expert precision T_m       [16*D]
+    int ev[MOPOE_MAX_MODS];      // exp(logvar_m)              [16*D]
+    int zj[MOPOE_MAX_JOBS];      // decoder input              [16][ld_z]
+    int gzj[MOPOE_MAX_JOBS];     // its gradient
+    int epsc[MOPOE_MAX_JOBS], stdc[MOPOE_MAX_JOBS];  // content eps / std  [16*D]
+    int epss[MOPOE_MAX_JOBS], stds[MOPOE_MAX_JOBS];  // style eps / std    [16*s_m]
+    int red;                     // [waves][kStatStride]
     int total;
 };
 
 HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
                           LatentLds& L) {
-    int r0a = 0, r0b = 0, zcols = 0;
+    const int D = m.class_dim;
+    int hsz = 0, xsz = 0, zcols = 0, klt = st.num_subsets * kRows * D;
+    int jobs_of[MOPOE_MAX_MODS] = {0, 0, 0, 0, 0};
+    for (int j = 0; j < st.num_jobs; ++j) jobs_of[st.job_mod[j]]++;
     for (int i = 0; i < m.num_mods; ++i) {
-        L.hs[i] = r0a;
-        L.gx[i] = r0b;
+        L.hs[i] = hsz;
+        L.xs[i] = xsz;
+        L.klt_style[i] = klt;
         if ((st.present_mask >> i) & 1) {
-            r0a += kRows * kLdH;
-            r0b += kRows * ld_x_lds(m, i);
+            hsz += kRows * kLdH;
+            xsz += kRows * ld_x_lds(m, i);
             zcols += round_up(z_dim(m, i), 16);
+            klt += kRows * m.style_dim[i];
         }
     }
     L.ld_gzp = zcols + 4;
-    L.gzp = r0b;
-    r0b += kGzChunks * kRows * L.ld_gzp;
-    int off = r0a > r0b ? r0a : r0b;
-    for (int i = 0; i < m.num_mods; ++i) {
-        L.heads[i] = off;
-        L.gheads[i] = off;
-        if ((st.present_mask >> i) & 1) {
+    L.gzp = xsz;
+    L.klt = xsz;
+    for (int i = 0; i < m.num_mods; ++i) L.klt_style[i] += xsz;  // absolute
+    // the largest K-split that keeps the kernel inside the 160 KiB LDS budget
+    for (L.gz_chunks = 8;; L.gz_chunks /= 2) {
+        int gz = L.gz_chunks * kRows * L.ld_gzp;
+        if (gz < klt) gz = klt;
+        int off = xsz + gz > hsz ? xsz + gz : hsz;
+        for (int i = 0; i < m.num_mods; ++i) {
+            L.gx[i] = L.xs[i];
+            L.heads[i] = L.gheads[i] = L.tm[i] = L.ev[i] = off;
+            if (!((st.present_mask >> i) & 1)) continue;
+            if (jobs_of[i] > 1) {
+                L.gx[i] = off;
+                off += kRows * ld_x_lds(m, i);
+            }
+            L.heads[i] = off;
             off += kRows * ld_heads_lds(m, i);
             L.gheads[i] = off;
             off += kRows * ld_heads_lds(m, i);
+            L.tm[i] = off;
+            off += kRows * D;
+            L.ev[i] = off;
+            off += kRows * D;
         }
+        for (int j = 0; j < st.num_jobs; ++j) {
+            const int i = st.job_mod[j];
+            L.zj[j] = off;
+            off += kRows * ld_z_lds(m, i);
+            L.gzj[j] = off;
+            off += kRows * ld_z_lds(m, i);
+            L.epsc[j] = off;
+            off += kRows * D;
+            L.stdc[j] = off;
+            off += kRows * D;
+            L.epss[j] = off;
+            off += kRows * m.style_dim[i];
+            L.stds[j] = off;
+            off += kRows * m.style_dim[i];
+        }
+        off = round_up(off, 4);
+        L.red = off;
+        off += waves * kStatStride;
+        L.total = off;
+        if (off * 4 <= 160 * 1024 || L.gz_chunks == 1) break;
     }
-    for (int j = 0; j < st.num_jobs; ++j) {
-        int i = st.job_mod[j];
-        L.zj[j] = off;
-        off += kRows * ld_z_lds(m, i);
-        L.gzj[j] = off;
-        off += kRows * ld_z_lds(m, i);
-    }
-    L.red = off;
-    off += waves * kStatStride;
-    L.total = off;
 }
 
 // ---------------------------------------------------------------------------

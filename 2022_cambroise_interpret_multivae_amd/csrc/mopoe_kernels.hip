@@ -232,695 +232,7 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------
-// k_latent helpers
-// ---------------------------------------------------------------------------
-struct Experts {  // unimodal content posteriors of one (row, latent dim)
-    float mu[MOPOE_MAX_MODS];
-    float lv[MOPOE_MAX_MODS];
-    float T[MOPOE_MAX_MODS];  // precision 1/(exp(lv)+eps)  (mm_div.py:14-16)
-};
-
-DEV float pick(const float (&v)[MOPOE_MAX_MODS], int idx) {
-    float r = v[0];
-#pragma unroll
-    for (int i = 1; i < MOPOE_MAX_MODS; ++i) r = (idx == i) ? v[i] : r;
-    return r;
-}
-
-// member of a SLICES subset that owns batch row gn (utils/utils.py:63-85)
-DEV int slice_member(const mopoe_step& st, int s, int gn) {
-    const int E = __popc((unsigned)st.sub_mask[s]);
-    const int f = st.sub_f[s];
-    const int j = f > 0 ? min(gn / f, E - 1) : E - 1;
-    return st.sub_members[s][j];
-}
-
-// (mu, logvar) of subset s at one (row, dim): mm_div.poe (mm_div.py:13-20)
-// behind BaseMMVae.poe_fusion (BaseMMVae.py:109-122), or moe_fusion (:96-106).
-DEV void subset_dist(const mopoe_step& st, int s, const Experts& e, int gn, float& mu_s,
-                     float& lv_s, float& tsum_out) {
-    const int kind = st.sub_kind[s];
-    if (kind == MOPOE_SUB_SLICES) {
-        const int ms = slice_member(st, s, gn);
-        mu_s = pick(e.mu, ms);
-        lv_s = pick(e.lv, ms);
-        tsum_out = 1.f;
-        return;
-    }
-    const unsigned mask = st.sub_mask[s];
-    float musum = 0.f, tsum = 0.f;
-#pragma unroll
-    for (int i = 0; i < MOPOE_MAX_MODS; ++i)
-        if ((mask >> i) & 1) {
-            musum += e.mu[i] * e.T[i];
-            tsum += e.T[i];
-        }
-    if (kind == MOPOE_SUB_POE_PRIOR) {
-        const float tp = 1.f / (1.f + kPoeEps);  // exp(0) + eps
-        musum += 0.f * tp;
-        tsum += tp;
-    }
-    mu_s = musum / tsum;
-    lv_s = logf(1.f / tsum);
-    tsum_out = tsum;
-}
-
-DEV int joint_component(const mopoe_step& st, int gn) {
-    const int K = st.num_comp;
-    return st.comp_f > 0 ? min(gn / st.comp_f, K - 1) : K - 1;
-}
-
-DEV float job_eps_content(const KArgs& a, int j, int gn, int d, uint32_t step) {
-    const float* p = a.st.job_eps_content[j];
-    if (p) return p[(size_t)gn * a.mdl.class_dim + d];
-    return philox_normal(a.st.seed, step, a.st.job_stream[j],
-                         (uint32_t)(gn * a.mdl.class_dim + d));
-}
-
-DEV float job_eps_style(const KArgs& a, int j, int gn, int d, uint32_t step) {
-    const float* p = a.st.job_eps_style[j];
-    const int sd = a.mdl.style_dim[a.st.job_mod[j]];
-    if (p) return p[(size_t)gn * sd + d];
-    return philox_normal(a.st.seed, step, 64u + (uint32_t)j, (uint32_t)(gn * sd + d));
-}
-
-// ---------------------------------------------------------------------------
-// k_latent: grid = row tiles, block = 512 (8 waves).  See file header.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kLatentThreads) void k_latent(const KArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const mopoe_model& mdl = a.mdl;
-    const mopoe_step& st = a.st;
-    const mopoe_buffers& buf = a.buf;
-    const int tid = threadIdx.x, lane = tid & 63;
-    // wave id as a provably wave-uniform scalar (guide T20): everything derived
-    // from it stays in SGPRs and buffer descriptors need no waterfall loop
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = st.n, D = mdl.class_dim, M = mdl.num_mods;
-    const float* __restrict__ P = buf.params;
-    const int row_tiles = cdiv(N, kRows);
-    if ((int)blockIdx.x >= row_tiles) {
-        // L2 warmers.  A kernel starts with cold per-XCD L2s, and a single CU
-        // streams misses at only ~20 GB/s, so a row-tile workgroup that has to
-        // pull every encoder-head / decoder weight (twice) through its own CU
-        // is bound by that.  These extra workgroups -- the otherwise idle CUs --
-        // touch one slice of the weights each; blocks b and b+8 share an XCD
-        // (round-robin dispatch, speed only), so slice s is touched once per
-        // XCD and the row-tile workgroups then stream L2 hits.
-        const int pb = (int)blockIdx.x - row_tiles;
-        const int nslices = max(((int)gridDim.x - row_tiles) / 8, 1);
-        const int slice = pb / 8;
-        float sink = 0.f;
-        for (int m = 0; m < M; ++m) {
-            if (!((st.present_mask >> m) & 1)) continue;
-            const int cnt[2] = {heads_dim(mdl, m) * kHid, mdl.input_dim[m] * z_dim(mdl, m)};
-            const int off[2] = {mdl.off_wh[m], mdl.off_wd[m]};
-            for (int w = 0; w < 2; ++w) {
-                const int per = round_up(cdiv(cnt[w], nslices), 32);  // 128-byte lines
-                const int beg = slice * per, end = min(beg + per, cnt[w]);
-                // one 4-byte read per 128-byte line
-                for (int i = beg + tid * 32; i < end; i += kLatentThreads * 32)
-                    sink += P[off[w] + i];
-            }
-        }
-        asm volatile("" ::"v"(sink));
-        return;
-    }
-    const int n0 = blockIdx.x * kRows;
-    const float inv_n = 1.0f / (float)N;
-    const bool bwd = st.backward != 0;
-    const bool sample = st.sample != 0;
-    const uint32_t step_no = (uint32_t)buf.counters[0];
-
-    const LatentLds& L = a.lds;
-    float* red = lds + L.red;
-
-    // source rows of this lane's four accumulator rows (clamped: see the
-    // no-conditional-loads rule in mopoe_common.h)
-    int xrow[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int gn = n0 + 4 * (lane >> 4) + r;
-        xrow[r] = gn < N ? src_row(buf, gn) : -1;
-    }
-    const rsrc_t prsrc = make_rsrc(P, (size_t)mdl.num_floats * sizeof(float));
-
-    STAMP(buf, 0);
-    // ---- S0: hidden tiles -> LDS, zero the reduction scratch ---------------
-    for (int i = tid; i < kLatentWaves * kStatStride; i += kLatentThreads) red[i] = 0.f;
-    {
-        // 16 x 256 floats per modality = 2 float4 per thread; every load of
-        // every modality is issued before the first LDS store
-        constexpr int kPer = kRows * (kHid / 4) / kLatentThreads;
-        static_assert(kPer * kLatentThreads == kRows * (kHid / 4), "tile/threads");
-        f32x4 hv[MOPOE_MAX_MODS][kPer];
-#pragma unroll
-        for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
-            if (m < M && ((st.present_mask >> m) & 1)) {
-                const rsrc_t hr = make_rsrc(buf.hidden[m], (size_t)N * kHid * sizeof(float));
-#pragma unroll
-                for (int i = 0; i < kPer; ++i) {
-                    const int s = tid + i * kLatentThreads;
-                    const int r = s / (kHid / 4), k = (s % (kHid / 4)) * 4;
-                    hv[m][i] = ldg4(hr, (uint32_t)((n0 + r) * kHid + k) * 4u);  // 0 past N
-                }
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
-            if (m < M && ((st.present_mask >> m) & 1)) {
-#pragma unroll
-                for (int i = 0; i < kPer; ++i) {
-                    const int s = tid + i * kLatentThreads;
-                    const int r = s / (kHid / 4), k = (s % (kHid / 4)) * 4;
-                    *reinterpret_cast<f32x4*>(lds + L.hs[m] + r * kLdH + k) = hv[m][i];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    STAMP(buf, 1);
-
-    // ---- S1: encoder heads [style_mu|style_lv|class_mu|class_lv] ----------
-    {
-        auto get = [&](int idx, GemmUnit& u) -> bool {
-            int base = 0;
-            for (int m = 0; m < M; ++m) {
-                if (!((st.present_mask >> m) & 1)) continue;
-                const int nh = heads_dim(mdl, m), tiles = cdiv(nh, 16);
-                if (idx < base + tiles) {
-                    u.As = lds + L.hs[m];
-                    u.B = P + mdl.off_wh[m];
-                    u.lda = kLdH;
-                    u.ldb = kHid;
-                    u.ncols = nh;
-                    u.K = kHid;
-                    u.j0 = (idx - base) * 16;
-                    u.kbeg = 0;
-                    u.kend = kHid;
-                    u.vec = 1;
-                    u.tag = m;
-                    return true;
-                }
-                base += tiles;
-            }
-            return false;
-        };
-        auto pre = [&](const GemmUnit& u) -> f32x4 {
-            const int col = u.j0 + (lane & 15);
-            f32x4 e = {0.f, 0.f, 0.f, 0.f};
-            e[0] = ldg(prsrc, guard((uint32_t)(mdl.off_bh[u.tag] + col) * 4u, col < u.ncols));
-            return e;
-        };
-        auto epi = [&](const GemmUnit& u, f32x4 acc, f32x4 extra) {
-            const int m = u.tag, nh = u.ncols, ldh = ld_heads_lds(mdl, m);
-            const int col = u.j0 + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * (lane >> 4) + r, gn = n0 + row;
-                const float v = col < nh ? acc[r] + extra[0] : 0.f;
-                lds[L.heads[m] + row * ldh + col] = v;
-                if (col < nh && gn < N) buf.heads[m][(size_t)gn * nh + col] = v;
-            }
-        };
-        // W fragments of the first tile are requested before the hidden tiles
-        // have landed in LDS (S0's barrier sits inside run_units' first MFMA
-        // dependency only through LDS reads, so keep the barrier explicit)
-        run_units<true, 8>(wave, kLatentWaves, lane, get, pre, epi);
-    }
-    __syncthreads();
-    STAMP(buf, 2);
-
-    // ---- S2: subset fusion, KL, joint latent, reparameterisation ----------
-    for (int e0 = 0; e0 < kRows * D; e0 += kLatentThreads) {
-        const int e = e0 + tid;
-        const bool act = e < kRows * D;
-        const int row = act ? e / D : 0, d = act ? e - row * D : 0;
-        const int gn = n0 + row;
-        const bool valid = act && gn < N;
-        Experts ex;
-#pragma unroll
-        for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
-            ex.mu[m] = 0.f;
-            ex.lv[m] = 0.f;
-            ex.T[m] = 0.f;
-            if (m < M && ((st.present_mask >> m) & 1)) {
-                const float* hd = lds + L.heads[m] + row * ld_heads_lds(mdl, m) +
-                                  2 * mdl.style_dim[m];
-                ex.mu[m] = hd[d];
-                ex.lv[m] = hd[D + d];
-                ex.T[m] = 1.f / (expf(ex.lv[m]) + kPoeEps);
-            }
-        }
-        const int s_sel = st.comp_sub[joint_component(st, gn < N ? gn : 0)];
-        float jmu = 0.f, jlv = 0.f;
-        for (int s = 0; s < st.num_subsets; ++s) {
-            if (!st.sub_avail[s]) continue;
-            float mu_s, lv_s, tsum;
-            subset_dist(st, s, ex, gn, mu_s, lv_s, tsum);
-            if (valid) {
-                const size_t o = ((size_t)s * N + gn) * D + d;
-                buf.subsets_mu[o] = mu_s;
-                buf.subsets_logvar[o] = lv_s;
-            }
-            // kl_div.py:9: -0.5 * sum(1 - exp(lv) - mu^2 + lv); scaled at the end
-            const float t = valid ? (1.f - expf(lv_s) - mu_s * mu_s + lv_s) : 0.f;
-            const float ws = wave_sum(t);
-            if (lane == 0) red[wave * kStatStride + kPartKlSub + s] += ws;
-            if (st.joint_mode == MOPOE_JOINT_MIXTURE) {
-                if (s == s_sel) {
-                    jmu = mu_s;
-                    jlv = lv_s;
-                }
-            } else if (st.joint_mode == MOPOE_JOINT_EXPERT) {
-                if (s == st.expert_subset) {
-                    jmu = mu_s;
-                    jlv = lv_s;
-                }
-            }
-        }
-        if (st.joint_mode == MOPOE_JOINT_MEAN) {  // BaseMMVae.py:229
-            for (int k = 0; k < st.num_comp; ++k) {
-                float mu_s, lv_s, tsum;
-                subset_dist(st, st.comp_sub[k], ex, gn, mu_s, lv_s, tsum);
-                jmu += mu_s;
-                jlv += lv_s;
-            }
-            jmu /= (float)st.num_comp;
-            jlv /= (float)st.num_comp;
-        }
-        if (valid) {
-            buf.joint_mu[(size_t)gn * D + d] = jmu;
-            buf.joint_logvar[(size_t)gn * D + d] = jlv;
-        }
-        if (act) {
-            for (int j = 0; j < st.num_jobs; ++j) {
-                const int m = st.job_mod[j];
-                float zmu = jmu, zlv = jlv;
-                if (st.job_src[j] >= 0) {
-                    float tsum;
-                    subset_dist(st, st.job_src[j], ex, gn, zmu, zlv, tsum);
-                }
-                float z = zmu;
-                if (sample && valid)  // BaseMMVae.py:37-40: eps * std + mu
-                    z = job_eps_content(a, j, gn, d, step_no) * expf(0.5f * zlv) + zmu;
-                const int c = mdl.style_dim[m] + d;
-                lds[L.zj[j] + row * ld_z_lds(mdl, m) + c] = z;
-                if (valid)
-                    buf.z[m][((size_t)st.job_slot[j] * N + gn) * ldz_glb(mdl, m) + c] = z;
-            }
-        }
-    }
-    STAMP(buf, 10);
-    // style latents and their KL
-    for (int m = 0; m < M; ++m) {
-        if (!((st.present_mask >> m) & 1)) continue;
-        const int sd = mdl.style_dim[m];
-        const int ldh = ld_heads_lds(mdl, m);
-        for (int e0 = 0; e0 < kRows * sd; e0 += kLatentThreads) {
-            const int e = e0 + tid;
-            const bool act = e < kRows * sd;
-            const int row = act ? e / sd : 0, d = act ? e - row * sd : 0;
-            const int gn = n0 + row;
-            const bool valid = act && gn < N;
-            const float smu = lds[L.heads[m] + row * ldh + d];
-            const float slv = lds[L.heads[m] + row * ldh + sd + d];
-            const float t = valid ? (1.f - expf(slv) - smu * smu + slv) : 0.f;
-            const float ws = wave_sum(t);
-            if (lane == 0) red[wave * kStatStride + kPartKlStyle + m] += ws;
-            if (act) {
-                for (int j = 0; j < st.num_jobs; ++j) {
-                    if (st.job_mod[j] != m) continue;
-                    float z = smu;
-                    if (sample && valid)
-                        z = job_eps_style(a, j, gn, d, step_no) * expf(0.5f * slv) + smu;
-                    lds[L.zj[j] + row * ld_z_lds(mdl, m) + d] = z;
-                    if (valid)
-                        buf.z[m][((size_t)st.job_slot[j] * N + gn) * ldz_glb(mdl, m) + d] = z;
-                }
-            }
-        }
-    }
-    STAMP(buf, 11);
-    // zero the K padding of every z tile (A operand of the decoder GEMM)
-    for (int j = 0; j < st.num_jobs; ++j) {
-        const int m = st.job_mod[j];
-        const int zd = z_dim(mdl, m), zp = round_up(zd, 16) - zd, ldzs = ld_z_lds(mdl, m);
-        for (int e = tid; e < kRows * zp; e += kLatentThreads)
-            lds[L.zj[j] + (e / zp) * ldzs + zd + (e % zp)] = 0.f;
-    }
-    __syncthreads();
-    STAMP(buf, 3);
-
-    // ---- S3/S4: decoder + NLL, then d loss / d z, one pass at a time -------
-    // (joint_elbo / moe: a single pass over all present modalities; poe: the
-    // joint pass followed by one unimodal pass per present modality,
-    // run_epochs.py:104-128)
-    float* part = buf.partials + (size_t)blockIdx.x * partials_stride(mdl);
-    for (int jb = 0; jb < st.num_jobs;) {
-        int je = jb + 1;
-        while (je < st.num_jobs && st.job_stream[je] == st.job_stream[jb]) ++je;
-        // S3: x_hat = z Wd^T + bd; Gaussian NLL epilogue (modality.py:42-45)
-        {
-            auto get = [&](int idx, GemmUnit& u) -> bool {
-                int base = 0;
-                for (int j = jb; j < je; ++j) {
-                    const int m = st.job_mod[j];
-                    const int dm = mdl.input_dim[m], zd = z_dim(mdl, m);
-                    const int tiles = cdiv(dm, 16);
-                    if (idx < base + tiles) {
-                        u.As = lds + L.zj[j];
-                        u.B = P + mdl.off_wd[m];
-                        u.lda = ld_z_lds(mdl, m);
-                        u.ldb = zd;
-                        u.ncols = dm;
-                        u.K = zd;
-                        u.j0 = (idx - base) * 16;
-                        u.kbeg = 0;
-                        u.kend = round_up(zd, 16);
-                        u.vec = zd % 4 == 0;
-                        u.tag = j;
-                        return true;
-                    }
-                    base += tiles;
-                }
-                return false;
-            };
-            struct DecExtra {  // what the NLL epilogue reads from global memory
-                f32x4 x;
-                float bias, lvo;
-            };
-            auto pre = [&](const GemmUnit& u) -> DecExtra {
-                const int m = st.job_mod[u.tag], dm = u.ncols;
-                const int col = u.j0 + (lane & 15);
-                const bool colv = col < dm;
-                const rsrc_t xr = make_rsrc_max(buf.x[m]);
-                DecExtra e;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    e.x[r] = ldg(xr, guard((uint32_t)(xrow[r] * dm + col) * 4u,
-                                           colv & (xrow[r] >= 0)));
-                e.bias = ldg(prsrc, guard((uint32_t)(mdl.off_bd[m] + col) * 4u, colv));
-                e.lvo = ldg(prsrc, guard((uint32_t)(mdl.off_lvo[m] + col) * 4u, colv));
-                return e;
-            };
-            auto epi = [&](const GemmUnit& u, f32x4 acc, const DecExtra& ex) {
-                const f32x4 xv = ex.x;
-                const int j = u.tag, m = st.job_mod[j], dm = u.ncols;
-                const int ldxs = ld_x_lds(mdl, m);
-                const float coef = st.job_nll_coef[j] * inv_n;
-                const size_t rbase = (size_t)st.job_slot[j] * N;
-                const int col = u.j0 + (lane & 15);
-                const bool colv = col < dm;
-                const float bias = ex.bias, lvo = ex.lvo;
-                const float inv_var = expf(-lvo);
-                float nll = 0.f, glv = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * (lane >> 4) + r, gn = n0 + row;
-                    const bool valid = colv && gn < N;
-                    float g = 0.f;
-                    if (valid) {
-                        const float xhat = acc[r] + bias;
-                        const float diff = xv[r] - xhat;
-                        const float q = 0.5f * diff * diff * inv_var;
-                        nll += q + 0.5f * lvo + kHalfLog2Pi;
-                        glv += 0.5f - q;
-                        g = -diff * inv_var * coef;
-                        buf.loc[m][(rbase + gn) * dm + col] = xhat;
-                        if (bwd) buf.g_xhat[m][(rbase + gn) * dm + col] = g;
-                    }
-                    if (bwd) lds[L.gx[m] + row * ldxs + col] = g;
-                }
-                const float ws = wave_sum(nll);
-                if (lane == 0) red[wave * kStatStride + kPartNll + j] += ws;
-                if (bwd) {
-                    glv += __shfl_xor(glv, 16, kWave);
-                    glv += __shfl_xor(glv, 32, kWave);
-                    if (lane < 16 && colv)
-                        part[lvo_part_off(mdl, m) + st.job_slot[j] * lvo_slot_stride(mdl, m) +
-                             col] = glv * coef;
-                }
-            };
-            run_units<true, 4>(wave, kLatentWaves, lane, get, pre, epi);
-        }
-        STAMP(buf, 12);
-        if (!bwd) {
-            jb = je;
-            continue;
-        }
-        __syncthreads();
-        STAMP(buf, 4);
-        // S4: g_z = g_xhat Wd, K = d_m split in kGzChunks partial slabs
-        {
-            auto get = [&](int idx, GemmUnit& u) -> bool {
-                int base = 0, zoff = 0;
-                for (int j = jb; j < je; ++j) {
-                    const int m = st.job_mod[j];
-                    const int dm = mdl.input_dim[m], zd = z_dim(mdl, m);
-                    const int ct = cdiv(zd, 16), Kp = round_up(dm, 16);
-                    const int kch = round_up(cdiv(Kp, kGzChunks), 16);
-                    const int units = ct * kGzChunks;
-                    if (idx < base + units) {
-                        const int t = (idx - base) / kGzChunks, c = (idx - base) % kGzChunks;
-                        u.As = lds + L.gx[m];
-                        u.B = P + mdl.off_wd[m];
-                        u.lda = ld_x_lds(mdl, m);
-                        u.ldb = zd;
-                        u.ncols = zd;
-                        u.K = dm;
-                        u.j0 = t * 16;
-                        u.kbeg = min(c * kch, Kp);
-                        u.kend = min(u.kbeg + kch, Kp);
-                        u.vec = 0;
-                        u.tag = c;
-                        u.tag2 = zoff + t * 16;
-                        return true;
-                    }
-                    base += units;
-                    zoff += round_up(zd, 16);
-                }
-                return false;
-            };
-            auto pre = [&](const GemmUnit&) -> f32x4 {
-                const f32x4 e = {0.f, 0.f, 0.f, 0.f};
-                return e;
-            };
-            auto epi = [&](const GemmUnit& u, f32x4 acc, f32x4) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * (lane >> 4) + r;
-                    lds[L.gzp + (u.tag * kRows + row) * L.ld_gzp + u.tag2 + (lane & 15)] =
-                        acc[r];
-                }
-            };
-            run_units<false, 8>(wave, kLatentWaves, lane, get, pre, epi);
-        }
-        __syncthreads();
-        STAMP(buf, 5);
-        {
-            int zoff = 0;
-            for (int j = jb; j < je; ++j) {
-                const int m = st.job_mod[j];
-                const int zp = round_up(z_dim(mdl, m), 16), ldzs = ld_z_lds(mdl, m);
-                for (int e = tid; e < kRows * zp; e += kLatentThreads) {
-                    const int row = e / zp, c = e - row * zp;
-                    float s = 0.f;
-#pragma unroll
-                    for (int k = 0; k < kGzChunks; ++k)
-                        s += lds[L.gzp + (k * kRows + row) * L.ld_gzp + zoff + c];
-                    lds[L.gzj[j] + row * ldzs + c] = s;
-                }
-                zoff += zp;
-            }
-        }
-        __syncthreads();
-        jb = je;
-    }
-
-    STAMP(buf, 6);
-    if (bwd) {
-        // ---- S5: backward of reparameterisation, KL and subset fusion ------
-        for (int e0 = 0; e0 < kRows * D; e0 += kLatentThreads) {
-            const int e = e0 + tid;
-            if (e >= kRows * D) break;
-            const int row = e / D, d = e - row * D;
-            const int gn = n0 + row;
-            const bool valid = gn < N;
-            Experts ex;
-            float gmu[MOPOE_MAX_MODS], glv[MOPOE_MAX_MODS];
-#pragma unroll
-            for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
-                ex.mu[m] = ex.lv[m] = ex.T[m] = 0.f;
-                gmu[m] = glv[m] = 0.f;
-                if (m < M && ((st.present_mask >> m) & 1)) {
-                    const float* hd = lds + L.heads[m] + row * ld_heads_lds(mdl, m) +
-                                      2 * mdl.style_dim[m];
-                    ex.mu[m] = hd[d];
-                    ex.lv[m] = hd[D + d];
-                    ex.T[m] = 1.f / (expf(ex.lv[m]) + kPoeEps);
-                }
-            }
-            const int s_sel = st.comp_sub[joint_component(st, valid ? gn : 0)];
-            if (valid) {
-                for (int s = 0; s < st.num_subsets; ++s) {
-                    if (!st.sub_avail[s]) continue;
-                    // does anything flow into this subset?
-                    float kc = st.sub_kl_coef[s];
-                    bool used = kc != 0.f;
-                    for (int j = 0; j < st.num_jobs; ++j)
-                        used = used || (st.job_src[j] < 0 ? s == s_sel : st.job_src[j] == s);
-                    if (!used) continue;
-                    float mu_s, lv_s, tsum;
-                    subset_dist(st, s, ex, gn, mu_s, lv_s, tsum);
-                    // KL(N(mu, e^lv) || N(0,1)) / N, weighted (kl_div.py:9-13)
-                    float g_mu = kc * mu_s * inv_n;
-                    float g_lv = kc * 0.5f * (expf(lv_s) - 1.f) * inv_n;
-                    for (int j = 0; j < st.num_jobs; ++j) {
-                        const bool hit = st.job_src[j] < 0 ? s == s_sel : st.job_src[j] == s;
-                        if (!hit) continue;
-                        const int m = st.job_mod[j];
-                        const float gz =
-                            lds[L.gzj[j] + row * ld_z_lds(mdl, m) + mdl.style_dim[m] + d];
-                        g_mu += gz;
-                        if (sample)
-                            g_lv += gz * job_eps_content(a, j, gn, d, step_no) * 0.5f *
-                                    expf(0.5f * lv_s);
-                    }
-                    if (st.sub_kind[s] == MOPOE_SUB_SLICES) {
-                        const int ms = slice_member(st, s, gn);
-#pragma unroll
-                        for (int m = 0; m < MOPOE_MAX_MODS; ++m)
-                            if (m == ms) {
-                                gmu[m] += g_mu;
-                                glv[m] += g_lv;
-                            }
-                    } else {
-                        const unsigned mask = st.sub_mask[s];
-#pragma unroll
-                        for (int m = 0; m < MOPOE_MAX_MODS; ++m)
-                            if ((mask >> m) & 1) {
-                                gmu[m] += g_mu * ex.T[m] / tsum;
-                                const float gT = (g_mu * (ex.mu[m] - mu_s) - g_lv) / tsum;
-                                glv[m] += gT * (-ex.T[m] * ex.T[m] * expf(ex.lv[m]));
-                            }
-                    }
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
-                if (m < M && ((st.present_mask >> m) & 1)) {
-                    const int c = 2 * mdl.style_dim[m] + d;
-                    float* gh = lds + L.gheads[m] + row * ld_heads_lds(mdl, m);
-                    gh[c] = gmu[m];
-                    gh[c + D] = glv[m];
-                    if (valid) {
-                        float* o = buf.g_heads[m] + (size_t)gn * heads_dim(mdl, m);
-                        o[c] = gmu[m];
-                        o[c + D] = glv[m];
-                    }
-                }
-            }
-        }
-        for (int m = 0; m < M; ++m) {
-            if (!((st.present_mask >> m) & 1)) continue;
-            const int sd = mdl.style_dim[m], nh = heads_dim(mdl, m);
-            const int ldh = ld_heads_lds(mdl, m);
-            const float kc = st.style_kl_coef[m];
-            for (int e = tid; e < kRows * sd; e += kLatentThreads) {
-                const int row = e / sd, d = e - row * sd;
-                const int gn = n0 + row;
-                float g_mu = 0.f, g_lv = 0.f;
-                if (gn < N) {
-                    const float smu = lds[L.heads[m] + row * ldh + d];
-                    const float slv = lds[L.heads[m] + row * ldh + sd + d];
-                    g_mu = kc * smu * inv_n;
-                    g_lv = kc * 0.5f * (expf(slv) - 1.f) * inv_n;
-                    for (int j = 0; j < st.num_jobs; ++j) {
-                        if (st.job_mod[j] != m) continue;
-                        const float gz = lds[L.gzj[j] + row * ld_z_lds(mdl, m) + d];
-                        g_mu += gz;
-                        if (sample)
-                            g_lv += gz * job_eps_style(a, j, gn, d, step_no) * 0.5f *
-                                    expf(0.5f * slv);
-                    }
-                    buf.g_heads[m][(size_t)gn * nh + d] = g_mu;
-                    buf.g_heads[m][(size_t)gn * nh + sd + d] = g_lv;
-                }
-                lds[L.gheads[m] + row * ldh + d] = g_mu;
-                lds[L.gheads[m] + row * ldh + sd + d] = g_lv;
-            }
-            const int pad = round_up(nh, 16) - nh;
-            for (int e = tid; e < kRows * pad; e += kLatentThreads)
-                lds[L.gheads[m] + (e / pad) * ldh + nh + (e % pad)] = 0.f;
-        }
-        __syncthreads();
-        STAMP(buf, 7);
-
-        // ---- S6: g_pre = (g_heads Wh) * [h > 0] ---------------------------
-        {
-            auto get = [&](int idx, GemmUnit& u) -> bool {
-                int base = 0;
-                for (int m = 0; m < M; ++m) {
-                    if (!((st.present_mask >> m) & 1)) continue;
-                    if (idx < base + kHid / 16) {
-                        const int nh = heads_dim(mdl, m);
-                        u.As = lds + L.gheads[m];
-                        u.B = P + mdl.off_wh[m];
-                        u.lda = ld_heads_lds(mdl, m);
-                        u.ldb = kHid;
-                        u.ncols = kHid;
-                        u.K = nh;
-                        u.j0 = (idx - base) * 16;
-                        u.kbeg = 0;
-                        u.kend = round_up(nh, 16);
-                        u.vec = 0;
-                        u.tag = m;
-                        return true;
-                    }
-                    base += kHid / 16;
-                }
-                return false;
-            };
-            auto pre = [&](const GemmUnit& u) -> f32x4 {  // h, for the ReLU mask
-                const int col = u.j0 + (lane & 15);
-                const rsrc_t hr = make_rsrc(buf.hidden[u.tag], (size_t)N * kHid * sizeof(float));
-                f32x4 e;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)   // rows >= N are out of range
-                    e[r] = ldg(hr, (uint32_t)((n0 + 4 * (lane >> 4) + r) * kHid + col) * 4u);
-                return e;
-            };
-            auto epi = [&](const GemmUnit& u, f32x4 acc, f32x4 h) {
-                const int col = u.j0 + (lane & 15);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gn = n0 + 4 * (lane >> 4) + r;
-                    if (gn < N)
-                        buf.g_pre[u.tag][(size_t)gn * kHid + col] = h[r] > 0.f ? acc[r] : 0.f;
-                }
-            };
-#ifdef MOPOE_STAMPS
-            unsigned long long* usp =
-                (blockIdx.x == 0 && tid == 0)
-                    ? reinterpret_cast<unsigned long long*>(buf.stats + 64) + 32 : nullptr;
-            run_units<false, 6>(wave, kLatentWaves, lane, get, pre, epi, usp);
-#else
-            run_units<false, 6>(wave, kLatentWaves, lane, get, pre, epi);
-#endif
-        }
-    }
-    __syncthreads();
-    STAMP(buf, 8);
-    if (tid < kNumPart) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < kLatentWaves; ++w) s += red[w * kStatStride + tid];
-        part[tid] = s;
-    }
-    STAMP(buf, 9);
-}
+#include "mopoe_latent.inc"
 
 // Scalars of the step from the row tiles' partial sums, in a fixed order
 // (run_epochs.py:89-128, mm_div.py:92-111, kl_div.py:7-14).  One block.
@@ -1449,10 +761,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     }
     {
         ProfScope ps(MOPOE_KERNEL_LATENT, s);
-        // + L2 warmers on the CUs the row tiles leave idle (see k_latent)
-        const int warm = tiles < 128 ? 128 : 0;
-        hipLaunchKernelGGL(k_latent, dim3(tiles + warm), dim3(kLatentThreads), (size_t)lds, s,
-                           ka);
+        hipLaunchKernelGGL(k_latent, dim3(tiles), dim3(kLatentThreads), (size_t)lds, s, ka);
     }
     return check_launch("k_latent");
 }

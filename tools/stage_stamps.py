@@ -17,8 +17,9 @@ eng = mm.MoPoEEngine(spec, "cuda", seed=1)
 g = torch.Generator().manual_seed(0)
 x = {"clinical": torch.randn(256, 7, generator=g).cuda(),
      "rois": torch.randn(256, 444, generator=g).cuda()}
-names = ["S0 h->LDS", "S1 heads", "S2 fusion", "S3 decoder+nll", "S4 g_z",
-         "S4b reduce", "S5 bwd fusion", "S6 g_pre", "final partials"]
+names = ["S0 h->LDS", "S1 heads", "S2a combine+x", "S2b fusion", "S2c KL sums",
+         "S3 decoder+nll", "S4 g_z", "S4b sum (+pass end)", "S5 bwd fusion", "S6 g_pre",
+         "final partials"]
 for it in range(300):
     plan, ws = eng.train_step(x)
 torch.cuda.synchronize()
@@ -26,23 +27,13 @@ acc = None
 for it in range(20):
     plan, ws = eng.train_step(x)
     torch.cuda.synchronize()
-    raw = ws._stats_all[64:].cpu().view(torch.int64)[:26].view(13, 2)
-    st = raw[:10]
+    st = ws._stats_all[64:].cpu().view(torch.int64)[:24].view(12, 2)
     d = (st[1:] - st[:-1]).double()
-    extra = torch.stack([raw[10] - raw[2], raw[11] - raw[10], raw[12] - raw[3]]).double()
-    ex = extra if it == 0 else ex + extra
-    us = ws._stats_all[64:].cpu().view(torch.int64)[32:38].double()
-    ud = us[1:] - us[:-1]
-    uacc = ud if it == 0 else uacc + ud
     acc = d if acc is None else acc + d
 acc /= 20
 tot = acc[:, 0].sum().item()
 for nme, row in zip(names, acc):
     rt, mt = row[0].item(), row[1].item()
-    print("%-16s %7.2f us   clock %6.0f MHz" % (nme, rt / 100.0,
+    print("%-20s %7.2f us   clock %6.0f MHz" % (nme, rt / 100.0,
                                                  (mt / rt * 100.0) if rt else 0))
-print("%-16s %7.2f us" % ("total block 0", tot / 100.0))
-print("S6 wave0 unit0: issue-first-loads %.2f | get+issue-next %.2f | mma %.2f | epilogue %.2f | rest %.2f us" % tuple((uacc / 20 / 100.0).tolist()))
-ex /= 20
-for nme, row in zip(["S2 content (wave0)", "S2 style (wave0)", "S3 units (wave0)"], ex):
-    print("%-20s %7.2f us" % (nme, row[0].item() / 100.0))
+print("%-20s %7.2f us" % ("total block 0", tot / 100.0))
