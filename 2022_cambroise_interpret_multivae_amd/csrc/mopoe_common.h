@@ -59,6 +59,7 @@ struct LatentLds {
     int hs[MOPOE_MAX_MODS];      // R0: hidden tile            [16][kLdH]
     int xs[MOPOE_MAX_MODS];      // R0: input tile             [16][ld_x]
     int gx[MOPOE_MAX_MODS];      // g_xhat tile (= xs when decoded once)
+    int xs_early;                // x tiles have their own area and are loaded at kernel start
     int gzp, ld_gzp, gz_chunks;  // R0: g_z partials           [chunks][16][ld_gzp]
     int klt;                     // overlays gzp: KL terms     [subsets][16*D], then styles
     int klt_style[MOPOE_MAX_MODS];
@@ -72,6 +73,11 @@ struct LatentLds {
     int epss[MOPOE_MAX_JOBS], stds[MOPOE_MAX_JOBS];  // style eps / std    [16*s_m]
     int red;                     // [waves][kStatStride]
     int total;
+    // (not LDS) layout of a row tile's slot in `partials`, precomputed because a
+    // runtime-bound loop over the model dims inside the kernel gets auto-
+    // vectorised and then drags the whole argument block into scratch
+    int part_stride;
+    int lvo_off[MOPOE_MAX_MODS];
 };
 
 HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
@@ -92,14 +98,40 @@ HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
         }
     }
     L.ld_gzp = zcols + 4;
-    L.gzp = xsz;
-    L.klt = xsz;
-    for (int i = 0; i < m.num_mods; ++i) L.klt_style[i] += xsz;  // absolute
-    // the largest K-split that keeps the kernel inside the 160 KiB LDS budget
-    for (L.gz_chunks = 8;; L.gz_chunks /= 2) {
+    L.part_stride = partials_stride(m);
+    for (int i = 0; i < MOPOE_MAX_MODS; ++i) L.lvo_off[i] = i < m.num_mods ? lvo_part_off(m, i) : 0;
+    // Preferred: x tiles in their own area (loaded at kernel start, no extra
+    // round trip later) and the largest K-split; fall back until the kernel fits
+    // the 160 KiB LDS budget.
+    const int klt_rel = klt;
+    int xrel[MOPOE_MAX_MODS];
+    for (int i = 0; i < MOPOE_MAX_MODS; ++i) xrel[i] = i < m.num_mods ? L.xs[i] : 0;
+    for (int option = 0;; ++option) {
+        const int early_of[6] = {1, 1, 0, 0, 0, 0};
+        const int chunks_of[6] = {8, 4, 8, 4, 2, 1};
+        L.xs_early = early_of[option];
+        L.gz_chunks = chunks_of[option];
         int gz = L.gz_chunks * kRows * L.ld_gzp;
-        if (gz < klt) gz = klt;
-        int off = xsz + gz > hsz ? xsz + gz : hsz;
+        if (gz < klt_rel) gz = klt_rel;
+        int off;
+        if (L.xs_early) {  // [hs | ...] and [gzp/klt] share R0, xs follows
+            L.gzp = 0;
+            off = gz > hsz ? gz : hsz;
+            for (int i = 0; i < m.num_mods; ++i) L.xs[i] = off + xrel[i];
+            off += xsz;
+        } else {           // xs overlays hs, gzp/klt follow xs
+            for (int i = 0; i < m.num_mods; ++i) L.xs[i] = xrel[i];
+            L.gzp = xsz;
+            off = xsz + gz > hsz ? xsz + gz : hsz;
+        }
+        L.klt = L.gzp;
+        {
+            int ks = st.num_subsets * kRows * D;
+            for (int i = 0; i < m.num_mods; ++i) {
+                L.klt_style[i] = L.klt + ks;
+                if ((st.present_mask >> i) & 1) ks += kRows * m.style_dim[i];
+            }
+        }
         for (int i = 0; i < m.num_mods; ++i) {
             L.gx[i] = L.xs[i];
             L.heads[i] = L.gheads[i] = L.tm[i] = L.ev[i] = off;
@@ -136,7 +168,7 @@ HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
         L.red = off;
         off += waves * kStatStride;
         L.total = off;
-        if (off * 4 <= 160 * 1024 || L.gz_chunks == 1) break;
+        if (off * 4 <= 160 * 1024 || option == 5) break;
     }
 }
 

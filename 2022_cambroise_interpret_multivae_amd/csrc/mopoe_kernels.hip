@@ -49,6 +49,19 @@ constexpr float kPoeEps = 1e-8f;
     do {              \
     } while (0)
 #endif
+// Diagnostic build: counters[15] = k makes k_latent return after stage stamp k
+// (tools/stage_times.py).  NOTE: the early returns push the 128-VGPR kernel into
+// scratch spills, so the diagnostic build's absolute times are not the product's.
+#ifdef MOPOE_STAMPS
+#define STOP_AFTER(buf, i)                                     \
+    do {                                                       \
+        if ((buf).counters[15] == (i)) return;                 \
+    } while (0)
+#else
+#define STOP_AFTER(buf, i) \
+    do {                   \
+    } while (0)
+#endif
 
 struct KArgs {
     mopoe_model mdl;
@@ -235,51 +248,71 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
 #include "mopoe_latent.inc"
 
 // Scalars of the step from the row tiles' partial sums, in a fixed order
-// (run_epochs.py:89-128, mm_div.py:92-111, kl_div.py:7-14).  One block.
+// (run_epochs.py:89-128, mm_div.py:92-111, kl_div.py:7-14).  One block of 256
+// threads; one thread per scalar -- a single thread walking the descriptor
+// arrays pays one scalar-memory round trip per element and took ~11 us.
 DEV void finalize_stats(const KArgs& a, int tid) {
-    __shared__ float sums[kNumPart];
+    __shared__ float slab[4][kStatStride];
+    __shared__ float kld[kStatStride];      // scalar values, by partial index
+    __shared__ float contrib[kStatStride];  // their share of total_loss
+    __shared__ float jdc[MOPOE_MAX_SUBSETS];
     const mopoe_buffers& buf = a.buf;
-    const int tiles = cdiv(a.st.n, kRows);
-    const int stride = partials_stride(a.mdl);
-    if (tid < kNumPart) {
+    const mopoe_step& st = a.st;
+    const int tiles = cdiv(st.n, kRows);
+    const int stride = a.lds.part_stride;
+    {   // partial index p = tid % 64, tile slice = tid / 64; slices summed in order
+        const int p = tid & 63, sl = tid >> 6;
+        const int per = cdiv(tiles, 4);
         float s = 0.f;
-        for (int t = 0; t < tiles; ++t) s += buf.partials[(size_t)t * stride + tid];
-        sums[tid] = s;
+        if (p < kNumPart)
+            for (int t = sl * per; t < min((sl + 1) * per, tiles); ++t)
+                s += buf.partials[(size_t)t * stride + p];
+        slab[sl][p] = s;
     }
     __syncthreads();
-    if (tid == 0) {
-        const mopoe_step& st = a.st;
-        const float fn = (float)st.n;
-        float total = 0.f;
-        for (int s = 0; s < MOPOE_MAX_SUBSETS; ++s) {
-            float kld = 0.f;
+    const float fn = (float)st.n;
+    if (tid < kNumPart) {
+        const float sum = ((slab[0][tid] + slab[1][tid]) + slab[2][tid]) + slab[3][tid];
+        float v = 0.f, c = 0.f;
+        int out = -1;
+        if (tid < kPartKlStyle) {                       // KL of subset s
+            const int s = tid;
+            out = MOPOE_STAT_KLD_SUBSET + s;
             if (s < st.num_subsets && st.sub_avail[s]) {
-                kld = -0.5f * sums[kPartKlSub + s] / fn;
-                total += st.sub_kl_coef[s] * kld;
+                v = -0.5f * sum / fn;
+                c = st.sub_kl_coef[s] * v;
             }
-            buf.stats[MOPOE_STAT_KLD_SUBSET + s] = kld;
-        }
-        float jd = 0.f;
-        for (int k = 0; k < st.num_comp; ++k)
-            jd += st.comp_w[k] * (-0.5f * sums[kPartKlSub + st.comp_sub[k]] / fn);
-        buf.stats[MOPOE_STAT_JOINT_DIV] = jd;
-        for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
-            float kld = 0.f;
+        } else if (tid < kPartNll) {                    // KL of style m
+            const int m = tid - kPartKlStyle;
+            out = MOPOE_STAT_KLD_STYLE + m;
             if (m < a.mdl.num_mods && ((st.present_mask >> m) & 1) && a.mdl.style_dim[m] > 0) {
-                kld = -0.5f * sums[kPartKlStyle + m] / fn;
-                total += st.style_kl_coef[m] * kld;
+                v = -0.5f * sum / fn;
+                c = st.style_kl_coef[m] * v;
             }
-            buf.stats[MOPOE_STAT_KLD_STYLE + m] = kld;
-        }
-        for (int j = 0; j < MOPOE_MAX_JOBS; ++j) {
-            float nll = 0.f;
+        } else {                                        // NLL of decoder job j
+            const int j = tid - kPartNll;
+            out = MOPOE_STAT_NLL + j;
             if (j < st.num_jobs) {
-                nll = sums[kPartNll + j] / fn;
-                total += st.job_nll_coef[j] * nll;
+                v = sum / fn;
+                c = st.job_nll_coef[j] * v;
             }
-            buf.stats[MOPOE_STAT_NLL + j] = nll;
         }
+        kld[tid] = v;
+        contrib[tid] = c;
+        buf.stats[out] = v;
+    }
+    __syncthreads();
+    if (tid < MOPOE_MAX_SUBSETS)
+        jdc[tid] = tid < st.num_comp ? st.comp_w[tid] * kld[kPartKlSub + st.comp_sub[tid]] : 0.f;
+    __syncthreads();
+    if (tid == 0) {
+        float total = 0.f, jd = 0.f;
+#pragma unroll
+        for (int i = 0; i < kNumPart; ++i) total += contrib[i];
+#pragma unroll
+        for (int k = 0; k < MOPOE_MAX_SUBSETS; ++k) jd += jdc[k];
         buf.stats[MOPOE_STAT_TOTAL_LOSS] = total;
+        buf.stats[MOPOE_STAT_JOINT_DIV] = jd;
     }
 }
 
@@ -439,7 +472,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
     const int lb = b - w.total_tiles;
     if (lb < w.lvo_blocks) {
         const int tiles = cdiv(a.st.n, kRows);
-        const int stride = partials_stride(a.mdl);
+        const int stride = a.lds.part_stride;
         // d loss / d decoders.<m>.logvar: sum of the row tiles' partials
         int m = 0;
         while (lb >= w.lvo_block_begin[m + 1]) ++m;
@@ -449,7 +482,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
             int slots = 0;
             for (int j = 0; j < a.st.num_jobs; ++j) slots += a.st.job_mod[j] == m;
             for (int sl = 0; sl < slots; ++sl) {
-                const float* p = buf.partials + lvo_part_off(a.mdl, m) +
+                const float* p = buf.partials + a.lds.lvo_off[m] +
                                  sl * lvo_slot_stride(a.mdl, m) + col;
                 for (int t = 0; t < tiles; ++t) g += p[(size_t)t * stride];
             }
