@@ -341,129 +341,183 @@ struct WArgs {
     int32_t total_tiles;   // GEMM tiles
     int32_t lvo_blocks;    // blocks after the GEMM tiles
     int32_t fuse_adam;
+    int32_t tile_begin[3 * MOPOE_MAX_MODS + 1];
     WJob jobs[3 * MOPOE_MAX_MODS];
     int32_t lvo_block_begin[MOPOE_MAX_MODS + 1];
     mopoe_adam adam;
 };
 
-// One wave's share of a G^T X tile: rows [rbeg, rend) in rounds of 64, i.e. 16
-// G + 16 X values per lane in flight per round, all from clamped addresses
-// (no conditional loads) and masked afterwards.
+// One wave's share of a 32x32 block of G^T X: batch rows [rbeg, rend) in rounds
+// of 64.  Both operands are read 8 bytes per lane (two adjacent columns of one
+// batch row), all 32 loads of a round in flight together, from guarded offsets
+// (no conditional loads).  Lane (c = lane&15, q = lane>>4), MFMA step s of a
+// round covers batch rows rb+4s .. rb+4s+3 (row rb+4s+q in this lane):
+//   A fragments  G[r][i0 + 2c + ti]   -> output rows    i = i0 + 2*(4q'+reg) + ti
+//   B fragments  X[r][j0 + 2c + tj]   -> output columns j = j0 + 2c + tj
+// (column-interleaved 16x16 tiles, as in k_latent).  The bias gradient is the
+// column of an implicit all-ones feature at j == xcols.
 template <bool GATHER>
-DEV f32x4 wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int ldg_, int ldx,
-                     int ci, int cj, int rbeg, int rend, int q, bool iv, bool jv, bool jb) {
-    const float bfill = jb ? 1.f : 0.f;
-    auto load = [&](int rb, float (&av)[16], float (&bv)[16]) {
+DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int ldg_, int ldx,
+                    int gcols, int xcols, int i0, int j0, int rbeg, int rend, int lane,
+                    f32x4 (&acc)[2][2]) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int c = lane & 15, q = lane >> 4;
+    const int ci = i0 + 2 * c, cj = j0 + 2 * c;
+    // per-element validity of the two columns this lane reads (bit masks)
+    const uint32_t am0 = ci < gcols ? 0xFFFFFFFFu : 0u, am1 = ci + 1 < gcols ? 0xFFFFFFFFu : 0u;
+    const uint32_t bm0 = cj < xcols ? 0xFFFFFFFFu : 0u, bm1 = cj + 1 < xcols ? 0xFFFFFFFFu : 0u;
+    const float one0 = cj == xcols ? 1.f : 0.f, one1 = cj + 1 == xcols ? 1.f : 0.f;
+    for (int rb = rbeg; rb < rend; rb += 64) {
         int xrow[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int r = rb + 4 * s + q;
             xrow[s] = GATHER ? xrows[min(r, rend - 1)] : r;
         }
+        f32x2 av[16], bv[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int r = rb + 4 * s + q;
             const bool rv = r < rend;
-            av[s] = ldg(gr, guard((uint32_t)(r * ldg_ + ci) * 4u, rv & iv));
-            const float x = ldg(xr, guard((uint32_t)(xrow[s] * ldx + cj) * 4u, rv & jv));
-            bv[s] = x + (rv ? bfill : 0.f);  // x is 0 unless jv (hardware range check)
-        }
-    };
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-    float av[16], bv[16];
-    load(rbeg, av, bv);
-    for (int rb = rbeg; rb < rend; rb += 64) {
-        float an[16], bn[16];
-        load(rb + 64, an, bn);  // all out of range (zeros) past rend
-#pragma unroll
-        for (int s = 0; s < 16; s += 2) {
-            acc = mfma_16x16x4(av[s], bv[s], acc);
-            acc2 = mfma_16x16x4(av[s + 1], bv[s + 1], acc2);
+            av[s] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                        gr, guard((uint32_t)(r * ldg_ + ci) * 4u, rv & (ci < gcols)), 0, 0));
+            bv[s] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                        xr, guard((uint32_t)(xrow[s] * ldx + cj) * 4u, rv & (cj < xcols)), 0, 0));
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            av[s] = an[s];
-            bv[s] = bn[s];
+            const bool rv = rb + 4 * s + q < rend;
+            // columns past the end of a row hold the next row's values: mask them
+            const float a0 = av[s][0], a1 = av[s][1], b0 = bv[s][0], b1 = bv[s][1];
+            const float fa0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, a0) & am0);
+            const float fa1 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, a1) & am1);
+            const float fb0 =
+                __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, b0) & bm0) + (rv ? one0 : 0.f);
+            const float fb1 =
+                __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, b1) & bm1) + (rv ? one1 : 0.f);
+            acc[0][0] = mfma_16x16x4(fa0, fb0, acc[0][0]);
+            acc[0][1] = mfma_16x16x4(fa0, fb1, acc[0][1]);
+            acc[1][0] = mfma_16x16x4(fa1, fb0, acc[1][0]);
+            acc[1][1] = mfma_16x16x4(fa1, fb1, acc[1][1]);
         }
     }
-    return acc + acc2;
 }
 
+constexpr int kWgLd = 36;  // leading dim of a 32x32 partial block in LDS
+
 __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
-    __shared__ f32x4 redacc[4][kWave];
+    __shared__ __attribute__((aligned(16))) float blk[4][32 * kWgLd];
     const mopoe_buffers& buf = a.buf;
     const int tid = threadIdx.x, lane = tid & 63;
-    // wave id as a provably wave-uniform scalar (guide T20): everything derived
-    // from it stays in SGPRs and buffer descriptors need no waterfall loop
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform (T20)
     const int b = blockIdx.x;
     const bool fuse = w.fuse_adam != 0;
 
     if (b < w.total_tiles) {
+        // job of this block: compares against one contiguous table (a scan over
+        // the job structs would be a chain of dependent scalar loads)
         int ji = 0;
-        while (ji + 1 < w.njobs && b >= w.jobs[ji + 1].tile_begin) ++ji;
+#pragma unroll
+        for (int k = 1; k < 3 * MOPOE_MAX_MODS; ++k) ji += (k < w.njobs) & (b >= w.tile_begin[k]);
         const WJob& job = w.jobs[ji];
         const int t = b - job.tile_begin;
-        const int i0 = (t / job.tiles_j) * 16, j0 = (t % job.tiles_j) * 16;
-        const int R = job.R;
+        const int i0 = (t / job.tiles_j) * 32, j0 = (t % job.tiles_j) * 32;
+        const int R = job.R, gcols = job.gcols, xcols = job.xcols;
+
+        // epilogue ownership: thread -> output row i0 + tid/8, columns j0 + 4*(tid%8) ..+3
+        const int ei = i0 + (tid >> 3), ej = j0 + 4 * (tid & 7);
+        const int nvalid = ei < gcols ? min(xcols - ej, 4) : 0;   // weight columns
+        const bool has_b = (ei < gcols) & (xcols >= ej) & (xcols < ej + 4) & (job.off_b >= 0);
+        const int widx = job.off_w + ei * xcols + ej;
+        const int bidx = job.off_b + ei;
+        const size_t pbytes = (size_t)a.mdl.num_floats * sizeof(float);
+        const rsrc_t rp = make_rsrc(buf.params, pbytes);
+        const rsrc_t rm = make_rsrc(buf.exp_avg, pbytes);
+        const rsrc_t rv = make_rsrc(buf.exp_avg_sq, pbytes);
+        // Adam operands are requested first: they arrive while the GEMM runs.
+        // (16-byte reads; elements past the row end are neighbours, never written back)
+        f32x4 pp = {0.f, 0.f, 0.f, 0.f}, pm = pp, pv = pp;
+        float bp = 0.f, bm = 0.f, bv = 0.f;
+        AdamCoef ac;
+        if (fuse) {
+            ac = adam_coef_load(buf.counters, w.adam);
+            const uint32_t o = guard((uint32_t)widx * 4u, nvalid > 0);
+            pp = ldg4(rp, o);
+            pm = ldg4(rm, o);
+            pv = ldg4(rv, o);
+            const uint32_t ob = guard((uint32_t)bidx * 4u, has_b);
+            bp = ldg(rp, ob);
+            bm = ldg(rm, ob);
+            bv = ldg(rv, ob);
+        }
+
         const int rq = round_up(cdiv(R, 4), 4);
         const int rbeg = wave * rq, rend = min(rbeg + rq, R);
-        const int ci = i0 + (lane & 15), cj = j0 + (lane & 15), q = lane >> 4;
-        const bool iv = ci < job.gcols;
-        const bool jv = cj < job.xcols, jb = cj == job.xcols;
-
-        // wave 0 owns the epilogue: its parameter / moment values are
-        // requested first so the Adam update does not wait on them later
-        int idx[4];
-        float pp[4], pm[4], pv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = i0 + 4 * q + r;
-            const int iw = job.off_w + i * job.xcols + cj;
-            const int ib = job.off_b + i;
-            int id = jv ? iw : ((jb && job.off_b >= 0) ? ib : -1);
-            idx[r] = i < job.gcols ? id : -1;
-            pp[r] = pm[r] = pv[r] = 0.f;
-        }
-        if (fuse && wave == 0) {
-            const size_t pbytes = (size_t)a.mdl.num_floats * sizeof(float);
-            const rsrc_t rp = make_rsrc(buf.params, pbytes);
-            const rsrc_t rm = make_rsrc(buf.exp_avg, pbytes);
-            const rsrc_t rv = make_rsrc(buf.exp_avg_sq, pbytes);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t o = guard((uint32_t)idx[r] * 4u, idx[r] >= 0);
-                pp[r] = ldg(rp, o);
-                pm[r] = ldg(rm, o);
-                pv[r] = ldg(rv, o);
-            }
-        }
-
         const rsrc_t gr = make_rsrc(job.G, (size_t)R * job.ldg * sizeof(float));
         const rsrc_t xr = make_rsrc_max(job.X);
-        const f32x4 acc =
-            job.xrows ? wgrad_rows<true>(gr, xr, job.xrows, job.ldg, job.ldx, ci, cj, rbeg,
-                                         rend, q, iv, jv, jb)
-                      : wgrad_rows<false>(gr, xr, nullptr, job.ldg, job.ldx, ci, cj, rbeg,
-                                          rend, q, iv, jv, jb);
-        const f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-        redacc[wave][lane] = acc + acc2;
-        __syncthreads();
-        if (wave == 0) {
-            f32x4 g = redacc[0][lane];
-            g += redacc[1][lane];
-            g += redacc[2][lane];
-            g += redacc[3][lane];
-            AdamCoef ac;
-            if (fuse) ac = adam_coef_load(buf.counters, w.adam);
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[2][2] = {{z4, z4}, {z4, z4}};
+        if (job.xrows)
+            wgrad_rows<true>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0, rbeg, rend,
+                             lane, acc);
+        else
+            wgrad_rows<false>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0, rbeg, rend,
+                              lane, acc);
+        // this wave's partial block -> LDS as [i][j]
+        {
+            const int c = lane & 15, q = lane >> 4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (idx[r] < 0) continue;
-                buf.grads[idx[r]] = g[r];
-                if (fuse)
-                    adam_update(ac, g[r], pp[r], pm[r], pv[r], buf.params + idx[r],
-                                buf.exp_avg + idx[r], buf.exp_avg_sq + idx[r]);
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        blk[wave][(2 * (4 * q + r) + ti) * kWgLd + 2 * c + tj] = acc[ti][tj][r];
+        }
+        __syncthreads();
+        // fixed-order sum of the four partials, 4 consecutive columns per thread
+        const int li = tid >> 3, lj = 4 * (tid & 7);
+        f32x4 g = *reinterpret_cast<const f32x4*>(&blk[0][li * kWgLd + lj]);
+        g += *reinterpret_cast<const f32x4*>(&blk[1][li * kWgLd + lj]);
+        g += *reinterpret_cast<const f32x4*>(&blk[2][li * kWgLd + lj]);
+        g += *reinterpret_cast<const f32x4*>(&blk[3][li * kWgLd + lj]);
+        if (nvalid > 0) {
+            f32x4 np = pp, nm = pm, nv = pv;
+            if (fuse) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float po, mo, vo;
+                    adam_update(ac, g[e], pp[e], pm[e], pv[e], &po, &mo, &vo);
+                    np[e] = po;
+                    nm[e] = mo;
+                    nv[e] = vo;
+                }
             }
+            if (nvalid >= 4) {
+                *reinterpret_cast<f32x4*>(buf.grads + widx) = g;
+                if (fuse) {
+                    *reinterpret_cast<f32x4*>(buf.params + widx) = np;
+                    *reinterpret_cast<f32x4*>(buf.exp_avg + widx) = nm;
+                    *reinterpret_cast<f32x4*>(buf.exp_avg_sq + widx) = nv;
+                }
+            } else {
+                for (int e = 0; e < nvalid; ++e) {
+                    buf.grads[widx + e] = g[e];
+                    if (fuse) {
+                        buf.params[widx + e] = np[e];
+                        buf.exp_avg[widx + e] = nm[e];
+                        buf.exp_avg_sq[widx + e] = nv[e];
+                    }
+                }
+            }
+        }
+        if (has_b) {
+            const int e = xcols - ej;
+            const float gb = e == 0 ? g[0] : e == 1 ? g[1] : e == 2 ? g[2] : g[3];
+            buf.grads[bidx] = gb;
+            if (fuse)
+                adam_update(ac, gb, bp, bm, bv, buf.params + bidx, buf.exp_avg + bidx,
+                            buf.exp_avg_sq + bidx);
         }
         return;
     }
@@ -819,9 +873,10 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w) {
         };
         for (int k = 0; k < 3; ++k) {
             WJob& jb = jobs[k];
-            jb.tiles_j = cdiv(jb.xcols + 1, 16);  // + bias column
+            jb.tiles_j = cdiv(jb.xcols + 1, 32);  // + bias column
             jb.tile_begin = tile;
-            tile += cdiv(jb.gcols, 16) * jb.tiles_j;
+            w.tile_begin[w.njobs] = tile;
+            tile += cdiv(jb.gcols, 32) * jb.tiles_j;
             w.jobs[w.njobs++] = jb;
         }
     }
