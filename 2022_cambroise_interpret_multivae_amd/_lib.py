@@ -100,6 +100,7 @@ class Buffers(C.Structure):
         ("z", _ptr * MAX_MODS),
         ("loc", _ptr * MAX_MODS),
         ("stats", _ptr),
+        ("stats_host", _ptr),
         ("g_xhat", _ptr * MAX_MODS),
         ("g_heads", _ptr * MAX_MODS),
         ("g_pre", _ptr * MAX_MODS),
@@ -130,7 +131,7 @@ SYMBOLS = {
     "mopoe_train_step": (C.c_int, [C.POINTER(Model), C.POINTER(Step),
                                    C.POINTER(Buffers), C.POINTER(Adam), _ptr]),
     "mopoe_adam_step": (C.c_int, [C.POINTER(Model), _i32, C.POINTER(Buffers),
-                                  C.POINTER(Adam), _f32, _ptr]),
+                                  C.POINTER(Adam), _f32, _i32, _ptr]),
     "mopoe_linear": (C.c_int, [_ptr, _i32, _i32, _ptr, _ptr, _i32, _i32, _ptr,
                                _ptr]),
     "mopoe_poe": (C.c_int, [_ptr, _ptr, _i32, C.c_int64, _f32, _ptr, _ptr,

@@ -300,6 +300,7 @@ DEV void finalize_stats(const KArgs& a, int tid) {
         kld[tid] = v;
         contrib[tid] = c;
         buf.stats[out] = v;
+        if (buf.stats_host) buf.stats_host[out] = v;
     }
     __syncthreads();
     if (tid < MOPOE_MAX_SUBSETS)
@@ -313,6 +314,10 @@ DEV void finalize_stats(const KArgs& a, int tid) {
         for (int k = 0; k < MOPOE_MAX_SUBSETS; ++k) jd += jdc[k];
         buf.stats[MOPOE_STAT_TOTAL_LOSS] = total;
         buf.stats[MOPOE_STAT_JOINT_DIV] = jd;
+        if (buf.stats_host) {
+            buf.stats_host[MOPOE_STAT_TOTAL_LOSS] = total;
+            buf.stats_host[MOPOE_STAT_JOINT_DIV] = jd;
+        }
     }
 }
 
@@ -573,11 +578,13 @@ struct AdamSegs {
     int32_t end[2 * MOPOE_MAX_MODS];
     float grad_scale;
     mopoe_adam adam;
+    int32_t host_coef;   // coef below was computed on the host for a known step
+    AdamCoef coef;
 };
 
 __global__ __launch_bounds__(256) void k_adam(const mopoe_buffers buf, const AdamSegs s) {
     __shared__ AdamCoef sc;
-    if (threadIdx.x == 0) sc = adam_coef_load(buf.counters, s.adam);
+    if (threadIdx.x == 0) sc = s.host_coef ? s.coef : adam_coef_load(buf.counters, s.adam);
     __syncthreads();
     const AdamCoef ac = sc;
     const int beg = s.begin[blockIdx.y], end = s.end[blockIdx.y];
@@ -1016,7 +1023,7 @@ int mopoe_train_step(const mopoe_model* mdl, const mopoe_step* st, const mopoe_b
 }
 
 int mopoe_adam_step(const mopoe_model* mdl, int32_t present_mask, const mopoe_buffers* buf,
-                    const mopoe_adam* adam, float grad_scale, void* stream) {
+                    const mopoe_adam* adam, float grad_scale, int32_t step, void* stream) {
     if (!mdl || !buf || !adam) return fail(MOPOE_ERR_ARG, "null descriptor%s");
     if (!buf->params || !buf->grads || !buf->exp_avg || !buf->exp_avg_sq || !buf->counters)
         return fail(MOPOE_ERR_ARG, "null optimiser buffer%s");
@@ -1033,6 +1040,17 @@ int mopoe_adam_step(const mopoe_model* mdl, int32_t present_mask, const mopoe_bu
     if (sg.nseg == 0) return fail(MOPOE_ERR_ARG, "empty present_mask%s");
     sg.grad_scale = grad_scale;
     sg.adam = *adam;
+    if (step > 0) {  // same arithmetic as adam_coef(), done once on the host
+        const double b1 = (double)adam->beta1, b2 = (double)adam->beta2;
+        sg.host_coef = 1;
+        sg.coef.b2 = adam->beta2;
+        sg.coef.one_m_b1 = (float)(1.0 - b1);
+        sg.coef.one_m_b2 = (float)(1.0 - b2);
+        sg.coef.step_size = (float)((double)adam->lr / (1.0 - pow(b1, (double)step)));
+        sg.coef.bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)step));
+        sg.coef.eps = adam->eps;
+        sg.coef.pad = 0.f;
+    }
     {
         ProfScope ps(MOPOE_KERNEL_ADAM, static_cast<hipStream_t>(stream));
         hipLaunchKernelGGL(k_adam, dim3(128, sg.nseg), dim3(256), 0,

@@ -64,6 +64,7 @@ class MoPoEEngine:
         self.grad_views = spec.param_views(self.grads)
         self.seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1)
         self._calls = 0
+        self._host_step = 0     # mirror of counters[0] (training steps begun)
         self._ws = {}
         self._keep = None   # tensors the in-flight kernels read (x, eps)
         self.adam = L.Adam(spec.lr, spec.betas[0], spec.betas[1], spec.adam_eps)
@@ -105,8 +106,13 @@ class MoPoEEngine:
             self._ws[key] = ws
         return ws
 
-    def _buffers(self, ws, x, row_index):
+    def _buffers(self, ws, x, row_index, stats_host=None):
         b = L.Buffers()
+        if stats_host is not None:
+            if not stats_host.is_pinned() or stats_host.numel() < L.NUM_STATS:
+                raise ValueError("stats_host must be a pinned float32 tensor of >= %d"
+                                 % L.NUM_STATS)
+            b.stats_host = L.ptr(stats_host)
         b.params = L.ptr(self.params)
         b.grads = L.ptr(self.grads)
         b.exp_avg = L.ptr(self.exp_avg)
@@ -199,8 +205,12 @@ class MoPoEEngine:
         self._keep = (x, keep, row_index)
         return plan, ws
 
-    def train_step(self, batch, eps=None, row_index=None, apply_adam=True):
-        """mopoe_train_step: forward + backward (+ fused Adam)."""
+    def train_step(self, batch, eps=None, row_index=None, apply_adam=True,
+                   stats_host=None):
+        """mopoe_train_step: forward + backward (+ fused Adam).  `stats_host`:
+        a pinned host tensor the kernel writes the step's scalars into (the
+        per-step log without a copy on the stream; read it after a sync or a
+        few steps later)."""
         x, n, row_index = self._prepare(batch, row_index)
         plan = self.spec.plan(list(x.keys()), n, True, None, True, True)
         slots = max(plan.jobs_per_mod)
@@ -208,12 +218,13 @@ class MoPoEEngine:
         step = plan.c_step
         keep = self._bind_noise(plan, step, eps)
         step.seed = self.seed
-        buf = self._buffers(ws, x, row_index)
+        buf = self._buffers(ws, x, row_index, stats_host)
         adam = C.byref(self.adam) if apply_adam else None
         L.check(L.lib.mopoe_train_step(self.spec.c_model, step, buf, adam,
                                        L.stream_ptr()), "mopoe_train_step")
         self._keep = (x, keep, row_index)
         self.last_present_mask = step.present_mask
+        self._host_step += 1
         return plan, ws
 
     def adam_step(self, present_mask=None, grad_scale=1.0):
@@ -229,7 +240,8 @@ class MoPoEEngine:
         b.counters = L.ptr(self.counters)
         L.check(L.lib.mopoe_adam_step(self.spec.c_model, present_mask, b,
                                       C.byref(self.adam), grad_scale,
-                                      L.stream_ptr()), "mopoe_adam_step")
+                                      self._host_step, L.stream_ptr()),
+                "mopoe_adam_step")
 
     # --------------------------------------------------------------- results
     def results(self, plan, ws):

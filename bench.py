@@ -9,8 +9,8 @@ style dims [3,20], batch 256 per GPU, float32 (exact-f32 MFMA), synthetic
 N(0,1) data -- a pool of 64 batches resident in HBM before the timed region
 -- random-init weights.  One step = encoder/decoder forward, MoPoE fusion,
 joint ELBO, full backward, (gradient all-reduce over RCCL when N > 1), Adam,
-and an asynchronous D2H copy of the step's scalar log (the reference logs
-every step, run_epochs.py:184).
+and the step's scalar log written by the kernel into pinned host memory (the
+reference logs every step, run_epochs.py:184).
 
 For N > 1 the driver launches one rank per GPU with torch.distributed.run;
 ranks are data-parallel replicas (weak scaling: 256 samples per GPU per
@@ -97,34 +97,43 @@ def make_pool(device):
     return pool
 
 
-def cpu_baseline(seconds=12.0):
+def cpu_baseline(seconds=10.0):
     """The oracle's train step (forward, loss, autograd backward, Adam) on the
-    host cores: a bounded sample of the same workload."""
+    host cores: a bounded sample of the same workload, at two thread counts
+    (these ~2,600 tiny ops do not scale with threads; the better one is `value`)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mopoe_oracle as mo
     cfg = mo.Config(NAMES, DIMS, STYLE, class_dim=LATENT)
-    params = mo.init_params(cfg, 0)
-    state = mo.adam_init(params)
     g = torch.Generator().manual_seed(1234)
     pool = [{n: torch.randn(BATCH, d, generator=g) for n, d in zip(NAMES, DIMS)}
             for _ in range(8)]
-    noise = mo.Noise(generator=mo.noise_rng(0))
-    for i in range(5):
-        mo.train_step(params, cfg, pool[i % 8], noise, state)
-        noise.tape.clear()
-    t0 = time.perf_counter()
-    steps = 0
-    while time.perf_counter() - t0 < seconds:
-        mo.train_step(params, cfg, pool[steps % 8], noise, state)
-        noise.tape.clear()
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(BATCH * steps / dt, 1), "unit": "samples/s",
-            "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d steps of the same bs-%d joint_elbo step (oracle/"
-                      "mopoe_oracle.py, PyTorch CPU float32, %d threads) in "
-                      "%.1f s" % (steps, BATCH, torch.get_num_threads(), dt),
-            "ms_per_step": round(1e3 * dt / steps, 3)}
+    share = min(16, os.cpu_count() or 1)   # the GPU box's CPU share for one GPU
+    runs = {}
+    for threads in (share, 1):
+        torch.set_num_threads(threads)
+        params = mo.init_params(cfg, 0)
+        state = mo.adam_init(params)
+        noise = mo.Noise(generator=mo.noise_rng(0))
+        for i in range(5):
+            mo.train_step(params, cfg, pool[i % 8], noise, state)
+            noise.tape.clear()
+        t0 = time.perf_counter()
+        steps = 0
+        while time.perf_counter() - t0 < seconds / 2:
+            mo.train_step(params, cfg, pool[steps % 8], noise, state)
+            noise.tape.clear()
+            steps += 1
+        dt = time.perf_counter() - t0
+        runs[threads] = (BATCH * steps / dt, steps, dt)
+    best = max(runs, key=lambda k: runs[k][0])
+    v, steps, dt = runs[best]
+    return {"value": round(v, 1), "unit": "samples/s", "cores": best, "kind": "port",
+            "sample": "%d steps of the same bs-%d joint_elbo train step (oracle/"
+                      "mopoe_oracle.py: PyTorch-CPU float32 restatement of the reference "
+                      "step, autograd backward, Adam) in %.1f s with %d thread(s); "
+                      "host has %d logical CPUs" % (steps, BATCH, dt, best, os.cpu_count() or 0),
+            "ms_per_step": round(1e3 * dt / steps, 3),
+            "other_thread_counts": {str(k): round(v[0], 1) for k, v in runs.items()}}
 
 
 def main():
@@ -163,13 +172,13 @@ def main():
     fused = world == 1
 
     def step(i):
-        plan, ws = eng.train_step(pool[(i * world + rank) % POOL],
-                                  apply_adam=fused)
+        # the step's scalar log lands in a ring of pinned host buffers, written
+        # by the kernel itself (no copy on the stream)
+        plan, ws = eng.train_step(pool[(i * world + rank) % POOL], apply_adam=fused,
+                                  stats_host=None if args.no_log_copy else log_ring[i % 8])
         if not fused:
             dist.all_reduce(eng.grads)              # RCCL, one flat buffer
             eng.adam_step(grad_scale=1.0 / world)
-        if not args.no_log_copy:
-            log_ring[i % 8].copy_(ws.stats, non_blocking=True)
         return ws
 
     def barrier():
@@ -191,6 +200,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(ws.stats[0].item())
+    if not args.no_log_copy:   # the host ring must have received the same scalar
+        host = float(log_ring[(args.warmup + args.steps - 1) % 8][0])
+        if host != loss:
+            sys.exit("pinned-host log %r != device scalar %r" % (host, loss))
     if not (loss == loss and abs(loss) < 1e9):
         sys.exit("non-finite loss after the timed region: %r" % loss)
 
@@ -207,7 +220,7 @@ def main():
                                "style 3,20, batch 256 per GPU, Adam lr 0.002",
                    "global_batch": BATCH * world,
                    "parallelism": "dp%d" % world if world > 1 else "single",
-                   "log_copy_every_step": not args.no_log_copy,
+                   "host_log_every_step": not args.no_log_copy,
                    "final_loss": round(loss, 3)},
     }
 

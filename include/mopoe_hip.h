@@ -168,6 +168,11 @@ typedef struct mopoe_buffers {
     float* z[MOPOE_MAX_MODS];            /* (R_m, ldz_m) [style | content]     */
     float* loc[MOPOE_MAX_MODS];          /* (R_m, d_m)   decoder mean          */
     float* stats;                        /* (MOPOE_NUM_STATS)                  */
+    float* stats_host;                   /* optional: pinned HOST memory mapped
+                                            into the device; the step's scalars
+                                            are also written there by the kernel
+                                            itself (a log without a D2H copy on
+                                            the stream); NULL to skip           */
 
     float* g_xhat[MOPOE_MAX_MODS];       /* (R_m, d_m)   d loss / d loc        */
     float* g_heads[MOPOE_MAX_MODS];      /* (n, nh_m)                          */
@@ -227,11 +232,13 @@ int mopoe_train_step(const mopoe_model* model, const mopoe_step* step,
 /* Replaces torch.optim.Adam.step (experiment.py:256-279) on the flat buffer,
  * restricted to the segments of the modalities in present_mask (parameters
  * whose .grad is None are skipped by torch).  `grad_scale` multiplies the
- * gradient first (1/world_size after a sum all-reduce).  The step number t
- * is read from buf->counters[0]. */
+ * gradient first (1/world_size after a sum all-reduce).  `step` is the Adam
+ * step number t when the host knows it (bias corrections are then computed
+ * on the host); pass 0 to have the kernel read t from buf->counters[0]
+ * (what a captured graph needs). */
 int mopoe_adam_step(const mopoe_model* model, int32_t present_mask,
                     const mopoe_buffers* buf, const mopoe_adam* adam,
-                    float grad_scale, void* stream);
+                    float grad_scale, int32_t step, void* stream);
 
 /* Free functions of section 8b, float32 device tensors. */
 
