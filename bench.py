@@ -88,6 +88,21 @@ def kernel_models(spec, n, fused_adam):
     return out
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in
+    separate runs, gfx950 correction applied); None if no summary is there."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_corrected"]
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def make_pool(device):
     g = torch.Generator().manual_seed(1234)
     pool = []
@@ -145,6 +160,9 @@ def main():
                     help="leave the per-step async D2H of the scalar log out")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearse the multi-GPU step (process group, all-reduce, separate "
+                         "Adam kernel) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,7 +174,7 @@ def main():
                      "torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -169,7 +187,7 @@ def main():
     pool = make_pool(device)
     log_ring = [torch.empty(mm._lib.NUM_STATS, dtype=torch.float32).pin_memory()
                 for _ in range(8)]
-    fused = world == 1
+    fused = dist is None
 
     def step(i):
         # the step's scalar log lands in a ring of pinned host buffers, written
@@ -219,7 +237,7 @@ def main():
                                "train step, input_dims 7,444, latent 20, "
                                "style 3,20, batch 256 per GPU, Adam lr 0.002",
                    "global_batch": BATCH * world,
-                   "parallelism": "dp%d" % world if world > 1 else "single",
+                   "parallelism": "dp%d" % world if dist is not None else "single",
                    "host_log_every_step": not args.no_log_copy,
                    "final_loss": round(loss, 3)},
     }
@@ -251,7 +269,7 @@ def main():
             roof = {"bound": "hbm", "achieved": round(achieved, 2),
                     "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(achieved / PEAK_HBM_GBS, 5)}
-        roof.update({"traffic": None, "kernel": name,
+        roof.update({"traffic": pmc_traffic(name), "kernel": name,
                      "avg_us": round(avg_s * 1e6, 3),
                      "share_of_device_time": round(ms / total_ms, 3),
                      "kernels_avg_us": {k: round(v[1] / max(v[0], 1) * 1e3, 3)
