@@ -90,7 +90,7 @@ class Buffers(C.Structure):
         ("exp_avg_sq", _ptr),
         ("counters", _ptr),
         ("x", _ptr * MAX_MODS),
-        ("row_index", _ptr),
+        ("row_index", _ptr * MAX_MODS),
         ("hidden", _ptr * MAX_MODS),
         ("heads", _ptr * MAX_MODS),
         ("subsets_mu", _ptr),

@@ -71,8 +71,8 @@ struct KArgs {
 };
 static_assert(sizeof(KArgs) <= 3500, "kernel argument block too large");
 
-DEV int src_row(const mopoe_buffers& buf, int gn) {
-    return buf.row_index ? buf.row_index[gn] : gn;
+DEV int src_row(const mopoe_buffers& buf, int m, int gn) {
+    return buf.row_index[m] ? buf.row_index[m][gn] : gn;
 }
 
 // ---------------------------------------------------------------------------
@@ -831,7 +831,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         maxd = d > maxd ? d : maxd;
         LinGroup& g = la.g[la.ngroups++];
         g.X = ka.buf.x[m];
-        g.rows = ka.buf.row_index;
+        g.rows = ka.buf.row_index[m];
         g.W = ka.buf.params + mdl.off_w1[m];
         g.b = ka.buf.params + mdl.off_b1[m];
         g.Y = ka.buf.hidden[m];
@@ -871,7 +871,7 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w) {
         for (int j = 0; j < st.num_jobs; ++j) njobs_m += st.job_mod[j] == m;
         const int d = mdl.input_dim[m], nh = heads_dim(mdl, m), zd = z_dim(mdl, m);
         WJob jobs[3] = {
-            {ka.buf.g_pre[m], ka.buf.x[m], ka.buf.row_index, kHid, kHid, d, d, st.n,
+            {ka.buf.g_pre[m], ka.buf.x[m], ka.buf.row_index[m], kHid, kHid, d, d, st.n,
              mdl.off_w1[m], mdl.off_b1[m], 0, 0},
             {ka.buf.g_heads[m], ka.buf.hidden[m], nullptr, nh, nh, kHid, kHid, st.n,
              mdl.off_wh[m], mdl.off_bh[m], 0, 0},

@@ -118,10 +118,11 @@ class MoPoEEngine:
         b.exp_avg = L.ptr(self.exp_avg)
         b.exp_avg_sq = L.ptr(self.exp_avg_sq)
         b.counters = L.ptr(self.counters)
-        b.row_index = L.ptr(row_index)
         for m, name in enumerate(self.spec.names):
             if name in x:
                 b.x[m] = L.ptr(x[name])
+                if row_index is not None and row_index.get(name) is not None:
+                    b.row_index[m] = L.ptr(row_index[name])
             b.hidden[m] = L.ptr(ws.hidden[m])
             b.heads[m] = L.ptr(ws.heads[m])
             b.z[m] = L.ptr(ws.z[m])
@@ -139,25 +140,33 @@ class MoPoEEngine:
         return b
 
     def _prepare(self, batch, row_index):
+        """Device float32 inputs (run_epochs.py:85-86: .to(device).float()).
+        `row_index`: None, one int tensor (n,) shared by all modalities, or a
+        dict {modality: (n,) int tensor}: batch row i of modality m is row
+        row_index[m][i] of batch[m] (a gather out of resident cohort arrays)."""
         L.require_gpu()
         if not self._on_gpu:
             raise L.MopoeError("engine was created on %s" % self.device)
+        if row_index is not None and not isinstance(row_index, dict):
+            row_index = {name: row_index for name in batch}
+        if row_index is not None:
+            row_index = {k: v.to(self.device, dtype=torch.int32).contiguous()
+                         for k, v in row_index.items() if v is not None}
         x = OrderedDict()
         n = None
         for name, v in batch.items():
-            # run_epochs.py:85-86: .to(device).float()
             t = v.to(self.device, dtype=torch.float32).contiguous()
             m = self.spec.names.index(name)
             if t.dim() != 2 or t.shape[1] != self.spec.input_dim[m]:
                 raise ValueError("batch[%r] has shape %s, expected (N, %d)" % (
                     name, tuple(t.shape), self.spec.input_dim[m]))
             x[name] = t
-            rows = t.shape[0] if row_index is None else row_index.shape[0]
+            rows = t.shape[0]
+            if row_index is not None and name in row_index:
+                rows = row_index[name].shape[0]
             if n is not None and rows != n:
                 raise ValueError("modalities disagree on the batch size")
             n = rows
-        if row_index is not None:
-            row_index = row_index.to(self.device, dtype=torch.int32).contiguous()
         return x, n, row_index
 
     def _bind_noise(self, plan, step, eps):

@@ -1,0 +1,192 @@
+"""Mirror of the reference's multimodal_cohort/dataset.py for the input side
+of the hot path.
+
+* `MultimodalDataset`: the reference's per-subject view over per-modality
+  blocks (`idx_per_mod[mod][subject]` = row of that block, or None when the
+  subject lacks the modality; reference dataset.py:15-147), built from arrays
+  in memory or from the on-disk layout the reference's fetchers write
+  (`multiblock_idx_{train,test}.npz`, `{mod}_data.npy`).
+* `MissingModalitySampler`: batches whose samples all have the SAME set of
+  modalities, complete batches shuffled before incomplete ones, drawn with
+  np.random.choice without replacement (reference dataset.py:275-354; the
+  stratified variant needs `iterstrat`, which is not in the image).
+* `ResidentCohort`: the MI355X-native input path.  The reference pushes every
+  sample through `torch.tensor -> StandardScaler.transform -> ...` in freshly
+  forked DataLoader workers; here each block is scaled once, uploaded once,
+  and a batch is a vector of row indices -- the kernels gather the rows
+  themselves (`row_index` of the C ABI), so an epoch moves no sample data.
+"""
+import copy
+from itertools import chain, combinations
+
+import numpy as np
+import torch
+
+
+class MultimodalDataset(torch.utils.data.Dataset):
+    def __init__(self, data, idx_per_mod, metadata=None, indices=None,
+                 on_the_fly_transform=None):
+        self.data = {k: np.asarray(v) for k, v in data.items()}
+        self.idx_per_mod = {k: np.asarray(v, dtype=object) for k, v in idx_per_mod.items()}
+        self.modalities = list(self.idx_per_mod)
+        n_samples = [len(self.idx_per_mod[key]) for key in self.modalities]
+        if len(set(n_samples)) != 1:
+            raise ValueError("All modalities do not have the same number of samples.")
+        self.metadata = metadata
+        if metadata is not None and len(metadata) != n_samples[0]:
+            raise ValueError("The data and metadata do not have the same number of samples.")
+        self.n_samples = n_samples[0]
+        self.indices = indices
+        self.on_the_fly_transform = on_the_fly_transform
+        self.modality_subsets = list(chain.from_iterable(
+            combinations(self.modalities, n) for n in range(1, len(self.modalities) + 1)))
+        self.idx_per_modality_subset = self.compute_idx_per_modality_subset()
+
+    @classmethod
+    def from_files(cls, idx_path, metadata=None, indices=None):
+        """The on-disk layout of the reference (dataset.py:23,54-90): an .npz of
+        object arrays (row index or None per subject) next to `{mod}_data.npy`.
+        The index file is the user's own data; it holds Python `None`s, hence
+        allow_pickle."""
+        idx_per_mod = dict(np.load(idx_path, allow_pickle=True))
+        data_path = idx_path.replace("idx", "data").replace(".npz", ".npy")
+        data_path = data_path.replace("_train", "").replace("_test", "")
+        data = {mod: np.load(data_path.replace("multiblock", mod), mmap_mode="r")
+                for mod in idx_per_mod}
+        return cls(data, idx_per_mod, metadata=metadata, indices=indices)
+
+    def __len__(self):
+        return len(self.indices) if self.indices is not None else self.n_samples
+
+    def _true_idx(self, idx):
+        return self.indices[idx] if self.indices is not None else idx
+
+    def __getitem__(self, idx):
+        idx = self._true_idx(idx)
+        ret = {}
+        for mod in self.modalities:
+            row = self.idx_per_mod[mod][idx]
+            if row is not None:
+                v = torch.as_tensor(np.array(self.data[mod][int(row)]))
+                t = self.on_the_fly_transform
+                if t is not None:
+                    v = t[mod](v) if isinstance(t, dict) and mod in t else (
+                        v if isinstance(t, dict) else t(v))
+                ret[mod] = v
+        metadata = {}
+        if self.metadata is not None:
+            metadata = self.metadata.iloc[idx].to_dict()
+        label = metadata["asd"] - 1 if "asd" in metadata else 0
+        return ret, label, metadata
+
+    def compute_idx_per_modality_subset(self):
+        """reference dataset.py:128-144"""
+        out = [[] for _ in self.modality_subsets]
+        for idx in range(len(self)):
+            true_idx = self._true_idx(idx)
+            mods = tuple(m for m in self.modalities
+                         if self.idx_per_mod[m][true_idx] is not None)
+            for sub_idx, subset in enumerate(self.modality_subsets):
+                if set(subset) == set(mods):
+                    out[sub_idx].append(idx)
+                    break
+        return out
+
+    def get_modality_proportions(self):
+        return [len(s) / len(self) for s in self.idx_per_modality_subset]
+
+
+class MissingModalitySampler(torch.utils.data.Sampler):
+    """reference dataset.py:275-354 (non-stratified path)."""
+
+    def __init__(self, dataset, batch_size, indices=None, stratify=None,
+                 discretize=None, seed=42):
+        if stratify is not None:
+            raise NotImplementedError("stratified batches need iterstrat "
+                                      "(MultilabelStratifiedKFold), absent from this image")
+        self.dataset = dataset
+        self.indices = indices
+        self.batch_size = batch_size
+        self.seed = seed
+
+    def __len__(self):
+        return sum((len(idx) + self.batch_size - 1) // self.batch_size
+                   for idx in self.dataset.idx_per_modality_subset)
+
+    def __iter__(self):
+        idx_per_modality_subset = copy.deepcopy(self.dataset.idx_per_modality_subset)
+        indices, complete, incomplete = [], [], []
+        batch_idx = 0
+        for idx, _ in enumerate(self.dataset.modality_subsets):
+            mod_subset_idx = idx_per_modality_subset[idx]
+            while len(mod_subset_idx) > 0:
+                size = min(len(mod_subset_idx), self.batch_size)
+                (incomplete if size < self.batch_size else complete).append(batch_idx)
+                new_indices = np.random.choice(mod_subset_idx, size=size, replace=False)
+                for i in new_indices:
+                    mod_subset_idx.remove(i)
+                indices.append(new_indices)
+                batch_idx += 1
+        complete_order = np.random.choice(complete, size=len(complete), replace=False)
+        incomplete_order = np.random.choice(incomplete, size=len(incomplete), replace=False)
+        ordered = [indices[i] for i in complete_order] + [indices[i] for i in incomplete_order]
+        return iter(ordered)
+
+
+class ResidentCohort:
+    """Per-modality blocks, scaled once and resident in HBM; batches are index
+    vectors.  `scalers` = {mod: (mean, scale)} reproduces the per-sample
+    StandardScaler.transform of the reference's on-the-fly transform
+    (experiment.py:228-232): (x - mean) / scale, in float32."""
+
+    def __init__(self, dataset, device, scalers=None):
+        self.dataset = dataset
+        self.device = torch.device(device)
+        self.x = {}
+        for mod in dataset.modalities:
+            arr = torch.as_tensor(np.ascontiguousarray(dataset.data[mod]), dtype=torch.float64)
+            if scalers is not None and mod in scalers:
+                mean, scale = scalers[mod]
+                arr = (arr - torch.as_tensor(mean, dtype=torch.float64)) / \
+                    torch.as_tensor(scale, dtype=torch.float64)
+            self.x[mod] = arr.to(torch.float32).to(self.device).contiguous()
+        # block row of every subject, -1 where the modality is missing
+        self.rows = {}
+        for mod in dataset.modalities:
+            col = dataset.idx_per_mod[mod]
+            self.rows[mod] = np.array([-1 if r is None else int(r) for r in col], dtype=np.int64)
+
+    def batch(self, sample_indices):
+        """(inputs, row_index) for engine.train_step / forward: the modalities
+        every sample of the batch has, and their block rows."""
+        idx = np.asarray(sample_indices, dtype=np.int64)
+        if self.dataset.indices is not None:
+            idx = np.asarray(self.dataset.indices)[idx]
+        inputs, row_index = {}, {}
+        for mod in self.dataset.modalities:
+            rows = self.rows[mod][idx]
+            if (rows >= 0).all():
+                inputs[mod] = self.x[mod]
+                row_index[mod] = torch.as_tensor(rows, dtype=torch.int32)
+            elif (rows >= 0).any():
+                raise ValueError("batch mixes samples with and without %r; use "
+                                 "MissingModalitySampler" % mod)
+        return inputs, row_index
+
+    def epoch(self, batch_size):
+        """One epoch of (inputs, row_index) in MissingModalitySampler order; all
+        index vectors go to the device in one transfer."""
+        batches = list(MissingModalitySampler(self.dataset, batch_size))
+        out = []
+        flat, spans = [], []
+        for b in batches:
+            inputs, row_index = self.batch(b)
+            for mod, r in row_index.items():
+                spans.append((len(out), mod, sum(len(f) for f in flat), len(r)))
+                flat.append(r)
+            out.append((inputs, {}))
+        if flat:
+            dev = torch.cat(flat).to(self.device, non_blocking=True)
+            for bi, mod, start, n in spans:
+                out[bi][1][mod] = dev[start:start + n]
+        return out

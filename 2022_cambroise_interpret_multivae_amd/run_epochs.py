@@ -64,16 +64,29 @@ def basic_routine_epoch(exp, model_idx, batch):
 
 
 def train(model_idx, epoch, exp, tb_logger):
-    """reference run_epochs.py:138-184"""
+    """reference run_epochs.py:138-184.  When `exp.dataset_train` is a
+    dataset.ResidentCohort the epoch runs on index batches over HBM-resident
+    blocks (no per-sample host work); otherwise batches come from a DataLoader
+    exactly as in the reference."""
     model, dataset, optimizer = exp.models, exp.dataset_train, exp.optimizers
     if exp.flags.num_models > 1:
         model, dataset, optimizer = model[model_idx], dataset[model_idx], optimizer[model_idx]
     model.train()
+    if getattr(exp.flags, "grad_scaling", False):
+        raise NotImplementedError("grad_scaling (the reference's branch never calls "
+                                  "zero_grad, SURVEY.md appendix C)")
+    if hasattr(dataset, "epoch"):                      # ResidentCohort
+        eng = model.engine
+        for inputs, row_index in dataset.epoch(exp.flags.batch_size):
+            optimizer._sync()
+            plan, ws = eng.train_step(inputs, row_index=row_index, apply_adam=True)
+            if tb_logger is not None:
+                sc = eng.scalars(plan, ws)
+                tb_logger.write_training_logs(eng.results(plan, ws), sc["total_loss"],
+                                              sc["log_probs"], sc["klds"])
+        return
     for batch in _loader(exp, dataset, train=True):
         basic_routine = basic_routine_epoch(exp, model_idx, batch)
-        if getattr(exp.flags, "grad_scaling", False):
-            raise NotImplementedError("grad_scaling (the reference's branch never calls "
-                                      "zero_grad, SURVEY.md appendix C)")
         optimizer.zero_grad()
         basic_routine["total_loss"].backward()
         optimizer.step()

@@ -157,7 +157,10 @@ typedef struct mopoe_buffers {
                                             [3..10] Adam coefficients of step [0] */
 
     const float* x[MOPOE_MAX_MODS];      /* (rows, d_m) input, ld = d_m        */
-    const int32_t* row_index;            /* optional (n): x row of batch row   */
+    const int32_t* row_index[MOPOE_MAX_MODS]; /* optional (n) per modality: row of
+                                            x[m] that holds batch row i (a batch
+                                            is then a gather out of cohort arrays
+                                            resident in HBM); NULL = identity   */
 
     float* hidden[MOPOE_MAX_MODS];       /* (n, 256)     relu(x W1^T + b1)     */
     float* heads[MOPOE_MAX_MODS];        /* (n, nh_m)    encoder outputs       */

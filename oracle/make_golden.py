@@ -266,6 +266,45 @@ def l0_vectors(ns):
     return store
 
 
+def sampler_vectors(ns):
+    """MissingModalitySampler of the reference on a synthetic cohort: which
+    subjects land in which batch, for a fixed numpy seed."""
+    import importlib
+    import types
+    from itertools import chain, combinations
+    ref_ds = importlib.import_module("multimodal_cohort.dataset")
+    rng = np.random.RandomState(3)
+    n = 101
+    has = {"clinical": rng.rand(n) > 0.15, "rois": rng.rand(n) > 0.25}
+    has["clinical"] |= ~has["rois"]          # every subject has at least one block
+    mods = ["clinical", "rois"]
+    subsets = list(chain.from_iterable(combinations(mods, k) for k in range(1, 3)))
+    per_subset = [[] for _ in subsets]
+    for i in range(n):
+        present = tuple(m for m in mods if has[m][i])
+        per_subset[subsets.index(present)].append(i)
+    ds = types.SimpleNamespace(modality_subsets=subsets, idx_per_modality_subset=per_subset,
+                               metadata=None)
+    store = OrderedDict()
+    store["has/clinical"] = has["clinical"]
+    store["has/rois"] = has["rois"]
+    def make_sampler(bs):
+        # the reference ctor calls Sampler.__init__(dataset), which torch 2.10
+        # no longer accepts (it is pinned to torch 1.13): set its fields directly
+        smp = ref_ds.MissingModalitySampler.__new__(ref_ds.MissingModalitySampler)
+        smp.dataset, smp.indices, smp.batch_size = ds, None, bs
+        smp.stratify, smp.discretize, smp.seed = None, None, 42
+        return smp
+
+    for seed, bs in ((7, 16), (11, 32), (5, 200)):
+        np.random.seed(seed)
+        batches = list(make_sampler(bs))
+        store["batches/%d_%d" % (seed, bs)] = np.array(json.dumps(
+            [[int(i) for i in b] for b in batches]))
+        store["len/%d_%d" % (seed, bs)] = np.array(len(make_sampler(bs)))
+    return store
+
+
 def main():
     ns = rh.import_reference()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
@@ -285,6 +324,10 @@ def main():
         print("%-32s %8d B" % (c["case"], os.path.getsize(path)))
     store = l0_vectors(ns)
     path = os.path.join(GOLDEN_DIR, "l0_functions.npz")
+    np.savez_compressed(path, **store)
+    total += os.path.getsize(path)
+    store = sampler_vectors(ns)
+    path = os.path.join(GOLDEN_DIR, "sampler.npz")
     np.savez_compressed(path, **store)
     total += os.path.getsize(path)
     print("total %d B" % total)
