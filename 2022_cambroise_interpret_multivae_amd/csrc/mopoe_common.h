@@ -78,6 +78,8 @@ struct LatentLds {
     // vectorised and then drags the whole argument block into scratch
     int part_stride;
     int lvo_off[MOPOE_MAX_MODS];
+    int gz_off[MOPOE_MAX_JOBS];  // column of job j inside its pass's g_z partial slab
+    int single_pass;             // all decoder jobs belong to one pass
 };
 
 HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
@@ -98,6 +100,12 @@ HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
         }
     }
     L.ld_gzp = zcols + 4;
+    L.single_pass = st.num_jobs > 0 && st.job_stream[st.num_jobs - 1] == st.job_stream[0];
+    for (int j = 0, zo = 0; j < st.num_jobs; ++j) {
+        if (j > 0 && st.job_stream[j] != st.job_stream[j - 1]) zo = 0;
+        L.gz_off[j] = zo;
+        zo += round_up(z_dim(m, st.job_mod[j]), 16);
+    }
     L.part_stride = partials_stride(m);
     for (int i = 0; i < MOPOE_MAX_MODS; ++i) L.lvo_off[i] = i < m.num_mods ? lvo_part_off(m, i) : 0;
     // Preferred: x tiles in their own area (loaded at kernel start, no extra

@@ -31,37 +31,39 @@ constexpr int kLatentWaves = kLatentThreads / kWave;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 constexpr float kPoeEps = 1e-8f;
 
-// Diagnostic build only (-DMOPOE_STAMPS, libmopoe_hip_stamps.so): lane 0 of
-// block 0 records (s_memrealtime [100 MHz], s_memtime [shader clock]) at stage
-// boundaries into the floats behind the stats (never read by the kernels).
+// Diagnostic build only (-DMOPOE_STAMPS, libmopoe_hip_stamps.so): thread 0 of
+// block 0 parks the low words of s_memrealtime [100 MHz] and s_memtime [shader
+// clock] in unused LDS words at stage boundaries and copies them behind the
+// stats at the end (tools/stage_stamps.py).  Going through LDS matters: a stamp
+// that takes a pointer out of the argument block makes hipcc copy the block to
+// scratch, and any private segment triples this kernel's time.
 #ifdef MOPOE_STAMPS
-#define STAMP(buf, i)                                                              \
-    do {                                                                           \
-        if (blockIdx.x == 0 && threadIdx.x == 0) {                                 \
-            unsigned long long* sp_ =                                              \
-                reinterpret_cast<unsigned long long*>((buf).stats + 64) + 2 * (i); \
-            sp_[0] = __builtin_amdgcn_s_memrealtime();                             \
-            sp_[1] = __builtin_amdgcn_s_memtime();                                 \
-        }                                                                          \
+#define STAMP(buf, i)                                                                  \
+    do {                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                     \
+            stamp_lds[(i) * kStatStride + 48] =                                        \
+                __uint_as_float((unsigned)__builtin_amdgcn_s_memrealtime());           \
+            stamp_lds[(i) * kStatStride + 49] =                                        \
+                __uint_as_float((unsigned)__builtin_amdgcn_s_memtime());               \
+        }                                                                              \
+    } while (0)
+#define STAMP_FLUSH(stats_ptr, n)                                                      \
+    do {                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x < 2 * (n))                                  \
+            (stats_ptr)[64 + threadIdx.x] =                                            \
+                stamp_lds[(threadIdx.x >> 1) * kStatStride + 48 + (threadIdx.x & 1)];  \
     } while (0)
 #else
 #define STAMP(buf, i) \
     do {              \
     } while (0)
-#endif
-// Diagnostic build: counters[15] = k makes k_latent return after stage stamp k
-// (tools/stage_times.py).  NOTE: the early returns push the 128-VGPR kernel into
-// scratch spills, so the diagnostic build's absolute times are not the product's.
-#ifdef MOPOE_STAMPS
-#define STOP_AFTER(buf, i)                                     \
-    do {                                                       \
-        if ((buf).counters[15] == (i)) return;                 \
+#define STAMP_FLUSH(stats_ptr, n) \
+    do {                          \
     } while (0)
-#else
+#endif
 #define STOP_AFTER(buf, i) \
     do {                   \
     } while (0)
-#endif
 
 struct KArgs {
     mopoe_model mdl;

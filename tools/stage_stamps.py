@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic: where k_latent spends its time.  Uses the -DMOPOE_STAMPS build
-(make -C 2022_cambroise_interpret_multivae_amd/csrc stamps):
-    MOPOE_LIB=libmopoe_hip_stamps.so python tools/stage_stamps.py
-Prints per-stage durations (100 MHz s_memrealtime) of block 0 and the shader
+(make -C 2022_cambroise_interpret_multivae_amd/csrc stamps), which must report
+ScratchSize 0 for the numbers to mean anything:
+    python tools/stage_stamps.py [method] [N]
+Prints per-stage durations of block 0 (100 MHz s_memrealtime) and the shader
 clock it ran at (delta s_memtime / delta s_memrealtime x 100 MHz)."""
 import os
 import sys
@@ -12,28 +13,30 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import mopoe_amd as mm  # noqa: E402
 
-spec = mm.ModelSpec(["clinical", "rois"], [7, 444], [3, 20])
+method = sys.argv[1] if len(sys.argv) > 1 else "joint_elbo"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+spec = mm.ModelSpec(["clinical", "rois"], [7, 444], [3, 20], method=method)
 eng = mm.MoPoEEngine(spec, "cuda", seed=1)
 g = torch.Generator().manual_seed(0)
-x = {"clinical": torch.randn(256, 7, generator=g).cuda(),
-     "rois": torch.randn(256, 444, generator=g).cuda()}
-names = ["S0 h->LDS", "S1 heads", "S2a combine+x", "S2b fusion", "S2c KL sums",
-         "S3 decoder+nll", "S4 g_z", "S4b sum (+pass end)", "S5 bwd fusion", "S6 g_pre",
-         "final partials"]
-for it in range(300):
-    plan, ws = eng.train_step(x)
+pool = [{"clinical": torch.randn(n, 7, generator=g).cuda(),
+         "rois": torch.randn(n, 444, generator=g).cuda()} for _ in range(8)]
+names = ["S0 h->LDS", "S1 heads", "S2a combine + x->LDS", "S2b fusion fwd",
+         "S3 decoder+NLL (+KL sums)", "S4 g_z partials", "S4b (poe only)", "S5 fusion bwd",
+         "S6 g_pre", "tail"]
+used = [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11]   # stamp 5 is no longer taken
+for i in range(300):
+    plan, ws = eng.train_step(pool[i % 8])
 torch.cuda.synchronize()
 acc = None
-for it in range(20):
-    plan, ws = eng.train_step(x)
+for it in range(40):
+    plan, ws = eng.train_step(pool[it % 8])
     torch.cuda.synchronize()
-    st = ws._stats_all[64:].cpu().view(torch.int64)[:24].view(12, 2)
-    d = (st[1:] - st[:-1]).double()
+    st = ws._stats_all[64:64 + 24].cpu().view(torch.int32).view(12, 2).double()[used]
+    d = (st[1:] - st[:-1]) % 4294967296.0
     acc = d if acc is None else acc + d
-acc /= 20
-tot = acc[:, 0].sum().item()
+acc /= 40
+print("k_latent stage times, %s, N=%d (block 0)" % (method, n))
 for nme, row in zip(names, acc):
     rt, mt = row[0].item(), row[1].item()
-    print("%-20s %7.2f us   clock %6.0f MHz" % (nme, rt / 100.0,
-                                                 (mt / rt * 100.0) if rt else 0))
-print("%-20s %7.2f us" % ("total block 0", tot / 100.0))
+    print("%-22s %6.2f us   clock %5.0f MHz" % (nme, rt / 100.0, (mt / rt * 100.0) if rt else 0))
+print("%-22s %6.2f us" % ("total", acc[:, 0].sum().item() / 100.0))
