@@ -59,22 +59,22 @@ class Step(C.Structure):
         ("expert_subset", _i32),
         ("backward", _i32),
         ("num_subsets", _i32),
-        ("sub_mask", _u8 * MAX_SUBSETS),
-        ("sub_avail", _u8 * MAX_SUBSETS),
-        ("sub_kind", _u8 * MAX_SUBSETS),
-        ("sub_members", (_u8 * MAX_MODS) * MAX_SUBSETS),
+        ("sub_mask", _i32 * MAX_SUBSETS),
+        ("sub_avail", _i32 * MAX_SUBSETS),
+        ("sub_kind", _i32 * MAX_SUBSETS),
+        ("sub_members", (_i32 * MAX_MODS) * MAX_SUBSETS),
         ("sub_f", _i32 * MAX_SUBSETS),
         ("sub_kl_coef", _f32 * MAX_SUBSETS),
         ("num_comp", _i32),
-        ("comp_sub", _u8 * MAX_SUBSETS),
+        ("comp_sub", _i32 * MAX_SUBSETS),
         ("comp_f", _i32),
         ("comp_w", _f32 * MAX_SUBSETS),
         ("style_kl_coef", _f32 * MAX_MODS),
         ("num_jobs", _i32),
-        ("job_mod", _u8 * MAX_JOBS),
-        ("job_slot", _u8 * MAX_JOBS),
-        ("job_src", C.c_int8 * MAX_JOBS),
-        ("job_stream", _u8 * MAX_JOBS),
+        ("job_mod", _i32 * MAX_JOBS),
+        ("job_slot", _i32 * MAX_JOBS),
+        ("job_src", _i32 * MAX_JOBS),
+        ("job_stream", _i32 * MAX_JOBS),
         ("job_nll_coef", _f32 * MAX_JOBS),
         ("job_eps_content", _ptr * MAX_JOBS),
         ("job_eps_style", _ptr * MAX_JOBS),

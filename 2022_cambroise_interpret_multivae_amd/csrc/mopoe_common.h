@@ -16,7 +16,7 @@ constexpr int kHid = MOPOE_HIDDEN;
 constexpr int kLdH = kHid + 4;       // LDS leading dim of a hidden tile
 constexpr int kStatStride = 64;      // floats reserved for scalar partials
 constexpr int kGzChunks = 4;         // K-split of the decoder data-gradient GEMM
-constexpr int kEncKChunk = 1024;     // K chunk of the encoder input tile in LDS
+constexpr int kEncKChunk = 512;      // K chunk of the encoder input tile in LDS
 
 // positions inside a row-tile's scalar partials
 constexpr int kPartKlSub = 0;                         // + subset
@@ -80,6 +80,17 @@ struct LatentLds {
     int lvo_off[MOPOE_MAX_MODS];
     int gz_off[MOPOE_MAX_JOBS];  // column of job j inside its pass's g_z partial slab
     int single_pass;             // all decoder jobs belong to one pass
+    // Unit tables (prefix sums): a wave finds the modality / job of its unit with a
+    // few scalar compares on one array instead of a scan of dependent scalar loads.
+    // Entries past the last modality / job repeat the total.
+    int s1_begin[MOPOE_MAX_MODS + 1];  // heads tiles (16 columns) of modality m
+    int sl_begin[MOPOE_MAX_MODS + 1];  // element-wise slots: [0] content slots, then
+                                       // the end of each modality's style slots
+    int s3_begin[MOPOE_MAX_JOBS + 1];  // decoder units (64 columns), all jobs
+    int s4_begin[MOPOE_MAX_JOBS + 1];  // g_z units (64 columns x gz_chunks), all jobs
+    int pass_end[MOPOE_MAX_JOBS];      // one past the last job of the pass starting here
+    int pres_mod[MOPOE_MAX_MODS];      // k-th present modality
+    int npres;
 };
 
 HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
@@ -178,6 +189,37 @@ HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
         L.total = off;
         if (off * 4 <= 160 * 1024 || option == 5) break;
     }
+    {
+        int t = 0, sl = cdiv(kRows * D, kWave);
+        L.npres = 0;
+        for (int i = 0; i < MOPOE_MAX_MODS; ++i) {
+            L.s1_begin[i] = t;
+            L.sl_begin[i] = sl;
+            L.pres_mod[i] = 0;
+            if (i < m.num_mods && ((st.present_mask >> i) & 1)) {
+                t += cdiv(heads_dim(m, i), 16);
+                sl += cdiv(kRows * m.style_dim[i], kWave);
+            }
+        }
+        for (int i = 0; i < m.num_mods; ++i)
+            if ((st.present_mask >> i) & 1) L.pres_mod[L.npres++] = i;
+        L.s1_begin[MOPOE_MAX_MODS] = t;
+        L.sl_begin[MOPOE_MAX_MODS] = sl;
+        int u3 = 0, u4 = 0;
+        for (int j = 0; j <= MOPOE_MAX_JOBS; ++j) {
+            L.s3_begin[j] = u3;
+            L.s4_begin[j] = u4;
+            if (j < st.num_jobs) {
+                u3 += cdiv(m.input_dim[st.job_mod[j]], 64);
+                u4 += cdiv(z_dim(m, st.job_mod[j]), 64) * L.gz_chunks;
+            }
+        }
+        for (int j = 0; j < MOPOE_MAX_JOBS; ++j) {
+            int je = j + 1;
+            while (je < st.num_jobs && st.job_stream[je] == st.job_stream[j]) ++je;
+            L.pass_end[j] = j < st.num_jobs ? je : j + 1;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -190,6 +232,15 @@ DEV f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     // A: lane l holds A[row l&15][k l>>4]; B: B[k l>>4][col l&15];
     // C/D: col = l&15, row = 4*(l>>4) + reg.
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// index of the segment of a prefix table (begin[0..NSEG]) that holds u
+template <int NSEG>
+DEV int find_seg(const int (&begin)[NSEG + 1], int u) {
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < NSEG; ++i) k += u >= begin[i];
+    return k;
 }
 
 DEV float wave_sum(float v) {

@@ -47,6 +47,15 @@ constexpr float kPoeEps = 1e-8f;
                 __uint_as_float((unsigned)__builtin_amdgcn_s_memtime());               \
         }                                                                              \
     } while (0)
+#define STAMPW(buf, i, w)                                                              \
+    do {                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == (w) * 64) {                              \
+            stamp_lds[(i) * kStatStride + 48] =                                        \
+                __uint_as_float((unsigned)__builtin_amdgcn_s_memrealtime());           \
+            stamp_lds[(i) * kStatStride + 49] =                                        \
+                __uint_as_float((unsigned)__builtin_amdgcn_s_memtime());               \
+        }                                                                              \
+    } while (0)
 #define STAMP_FLUSH(stats_ptr, n)                                                      \
     do {                                                                               \
         if (blockIdx.x == 0 && threadIdx.x < 2 * (n))                                  \
@@ -56,6 +65,9 @@ constexpr float kPoeEps = 1e-8f;
 #else
 #define STAMP(buf, i) \
     do {              \
+    } while (0)
+#define STAMPW(buf, i, w) \
+    do {                  \
     } while (0)
 #define STAMP_FLUSH(stats_ptr, n) \
     do {                          \
@@ -144,7 +156,12 @@ DEV void adam_update(const AdamCoef& c, float g, float p, float m, float v, floa
     *po = p - c.step_size * (m1 / denom);                 // addcdiv_(m, denom, -step)
 }
 
-__global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
+constexpr int kLinThreads = 512;  // 8 waves: 4 column tiles x 2 interleaved K halves
+constexpr int kLinRedFloats = 4 * kWave * 4;
+
+__global__ __launch_bounds__(kLinThreads) void k_linear(const LinArgs a_by_value) {
+    (void)a_by_value;  // read in place (see k_latent)
+    const LinArgs& a = *(const LinArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     // wave id as a provably wave-uniform scalar (guide T20): everything derived
@@ -163,10 +180,15 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
     if ((int)blockIdx.x * 64 >= g.ncols) return;
     const int K = g.K;
     const rsrc_t xr = make_rsrc_max(g.X);
-    const bool vecx = K % 4 == 0;   // 4-wide reads stay inside a row
-    const bool vecw = K % 4 == 0;
+    const bool vec = K % 4 == 0;   // 4-wide reads stay inside a row
     const int n0 = blockIdx.y * kRows;
-    const int j0 = (blockIdx.x * 4 + wave) * 16;
+    // The step is a chain of dependent latencies, so a tile's K axis is cut in two
+    // interleaved halves (fragment f of 16 k goes to half f & 1) owned by two
+    // waves, and a wave requests ALL its W fragments of a 512-deep stretch at
+    // once: one round trip to L2/HBM per wave for K <= 512, and an MFMA
+    // accumulation chain half as long.
+    const int tile = wave & 3, kh = wave >> 2;
+    const int j0 = (blockIdx.x * 4 + tile) * 16;
 
     // source row of each of the tile's 16 batch rows (gather resolved once)
     __shared__ int rowsel[kRows];
@@ -175,7 +197,7 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
         rowsel[tid] = g.rows ? g.rows[gn] : gn;
     }
     __syncthreads();
-    constexpr int CH = 8;     // W fragments per batch (8 x 16 k)
+    constexpr int CH = 16;     // W fragments per wave and batch
     constexpr int kStage = 4;  // float4 loads in flight per thread while staging
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     for (int kc0 = 0; kc0 < K; kc0 += kEncKChunk) {
@@ -183,31 +205,30 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
         const int Kp = round_up(Kc, 16);
         const int ldx = Kp + 4;
         const int q4 = Kp / 4;
-        GemmUnit u;
-        u.As = lds;
-        u.B = g.W + kc0;
-        u.lda = ldx;
-        u.ldb = K;
-        u.ncols = g.ncols;
-        u.K = Kc;
-        u.j0 = j0;
-        u.kbeg = 0;
-        u.kend = j0 < g.ncols ? Kp : 0;
-        u.vec = vecw;
+        const int kend = j0 < g.ncols ? Kp : 0;
+        const rsrc_t wr = make_rsrc(g.W + kc0, (size_t)g.ncols * K * sizeof(float));
+        auto load_w = [&](int i0, f32x4 (&b)[CH]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {  // k >= Kc is out of range -> 0
+                const int kb = 16 * (kh + 2 * (i0 + c));
+                b[c] = vec ? glb_b4_nt<true>(wr, K, Kc, j0, kb, lane)
+                           : glb_b4_nt<false>(wr, K, Kc, j0, kb, lane);
+            }
+        };
         // the wave's first batch of W fragments is in flight while the
         // workgroup stages the input tile
         f32x4 b[CH];
-        load_batch<true, CH>(u, 0, b, lane);
+        load_w(0, b);
         if (kc0 > 0) __syncthreads();
-        for (int s0 = 0; s0 < kRows * q4; s0 += kStage * 256) {
+        for (int s0 = 0; s0 < kRows * q4; s0 += kStage * kLinThreads) {
             f32x4 v[kStage];
 #pragma unroll
             for (int i = 0; i < kStage; ++i) {
-                const int s = s0 + i * 256 + tid;
+                const int s = s0 + i * kLinThreads + tid;
                 const int r = min(s / q4, kRows - 1), k = (s - (s / q4) * q4) * 4;
                 const bool rv = (s < kRows * q4) & (n0 + r < N);
                 const uint32_t base = (uint32_t)(rowsel[r] * g.ldx + kc0 + k) * 4u;
-                if (vecx) {
+                if (vec) {
                     v[i] = ldg4(xr, guard(base, rv & (k < Kc)));
                 } else {
 #pragma unroll
@@ -217,7 +238,7 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < kStage; ++i) {
-                const int s = s0 + i * 256 + tid;
+                const int s = s0 + i * kLinThreads + tid;
                 if (s < kRows * q4) {
                     const int r = s / q4, k = (s - r * q4) * 4;
                     *reinterpret_cast<f32x4*>(lds + r * ldx + k) = v[i];
@@ -225,15 +246,34 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a) {
             }
         }
         __syncthreads();
-        for (int kb = 0; kb < u.kend; kb += 16 * CH) {
+        for (int i0 = 0; 16 * (kh + 2 * i0) < kend; i0 += CH) {
             f32x4 bn[CH];
-            load_batch<true, CH>(u, kb + 16 * CH, bn, lane);  // clamped past the end
-            mma_batch<CH>(u, kb, b, acc, acc2, lane);
+            const bool more = 16 * (kh + 2 * (i0 + CH)) < kend;  // wave-uniform
+            if (more) load_w(i0 + CH, bn);
 #pragma unroll
-            for (int c = 0; c < CH; ++c) b[c] = bn[c];
+            for (int c = 0; c < CH; ++c) {
+                const int k = 16 * (kh + 2 * (i0 + c));
+                if (k < kend) {  // wave-uniform
+                    const f32x4 av = lds_a4(lds, ldx, k, lane);
+                    acc = mfma_16x16x4(av[0], b[c][0], acc);
+                    acc2 = mfma_16x16x4(av[1], b[c][1], acc2);
+                    acc = mfma_16x16x4(av[2], b[c][2], acc);
+                    acc2 = mfma_16x16x4(av[3], b[c][3], acc2);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) b[c] = bn[c];
+            }
         }
     }
     acc += acc2;
+    // the odd K half hands its partial tile over through LDS (behind the x tile)
+    float* red = lds + kRows * (round_up(min(K, kEncKChunk), 16) + 4);
+    if (kh == 1) *reinterpret_cast<f32x4*>(red + (tile * kWave + lane) * 4) = acc;
+    __syncthreads();
+    if (kh == 1) return;
+    acc += *reinterpret_cast<const f32x4*>(red + (tile * kWave + lane) * 4);
     const int col = j0 + (lane & 15);
     if (col >= g.ncols) return;
     const float bias = g.b ? g.b[col] : 0.f;
@@ -808,11 +848,11 @@ int latent_lds_bytes(const mopoe_model& mdl, const mopoe_step& st) {
 
 int launch_linear(const LinArgs& la, int max_k, int max_cols, hipStream_t s) {
     const int kp = round_up(max_k < kEncKChunk ? max_k : kEncKChunk, 16);
-    const size_t lds = (size_t)kRows * (kp + 4) * sizeof(float);
+    const size_t lds = ((size_t)kRows * (kp + 4) + kLinRedFloats) * sizeof(float);
     {
         ProfScope ps(MOPOE_KERNEL_LINEAR, s);
         hipLaunchKernelGGL(k_linear, dim3(cdiv(max_cols, 64), cdiv(la.n, kRows), la.ngroups),
-                           dim3(256), lds, s, la);
+                           dim3(kLinThreads), lds, s, la);
     }
     return check_launch("k_linear");
 }

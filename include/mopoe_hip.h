@@ -112,17 +112,17 @@ typedef struct mopoe_step {
     /* non-empty subsets in BaseExperiment.set_subsets order
      * (utils/BaseExperiment.py:58-79) */
     int32_t num_subsets;
-    uint8_t sub_mask[MOPOE_MAX_SUBSETS];   /* member bitmask                   */
-    uint8_t sub_avail[MOPOE_MAX_SUBSETS];  /* all members present              */
-    uint8_t sub_kind[MOPOE_MAX_SUBSETS];   /* MOPOE_SUB_*                      */
-    uint8_t sub_members[MOPOE_MAX_SUBSETS][MOPOE_MAX_MODS]; /* sorted-name order */
+    int32_t sub_mask[MOPOE_MAX_SUBSETS];   /* member bitmask                   */
+    int32_t sub_avail[MOPOE_MAX_SUBSETS];  /* all members present              */
+    int32_t sub_kind[MOPOE_MAX_SUBSETS];   /* MOPOE_SUB_*                      */
+    int32_t sub_members[MOPOE_MAX_SUBSETS][MOPOE_MAX_MODS]; /* sorted-name order */
     int32_t sub_f[MOPOE_MAX_SUBSETS];      /* SLICES: rows per member slice    */
     float sub_kl_coef[MOPOE_MAX_SUBSETS];  /* d loss / d KL(subset)            */
 
     /* mixture components = subsets passing fusion_condition
      * (utils/BaseMMVae.py:125-134,213-227); comp_f = int(floor(N*w_0)) */
     int32_t num_comp;
-    uint8_t comp_sub[MOPOE_MAX_SUBSETS];
+    int32_t comp_sub[MOPOE_MAX_SUBSETS];
     int32_t comp_f;
     float comp_w[MOPOE_MAX_SUBSETS];       /* reweighted weights (float32)     */
 
@@ -131,10 +131,10 @@ typedef struct mopoe_step {
     /* decoder jobs: job 0.. = joint pass (one per present modality); method
      * poe adds one unimodal job per present modality (run_epochs.py:104-128) */
     int32_t num_jobs;
-    uint8_t job_mod[MOPOE_MAX_JOBS];
-    uint8_t job_slot[MOPOE_MAX_JOBS];      /* row block inside z/loc/g_xhat    */
-    int8_t job_src[MOPOE_MAX_JOBS];        /* -1: joint latent, else subset    */
-    uint8_t job_stream[MOPOE_MAX_JOBS];    /* pass id, non-decreasing; jobs of
+    int32_t job_mod[MOPOE_MAX_JOBS];
+    int32_t job_slot[MOPOE_MAX_JOBS];      /* row block inside z/loc/g_xhat    */
+    int32_t job_src[MOPOE_MAX_JOBS];        /* -1: joint latent, else subset    */
+    int32_t job_stream[MOPOE_MAX_JOBS];    /* pass id, non-decreasing; jobs of
                                               a pass share the content eps    */
     float job_nll_coef[MOPOE_MAX_JOBS];    /* d loss / d nll(job)              */
 
