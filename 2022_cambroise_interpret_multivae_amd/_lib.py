@@ -58,6 +58,7 @@ class Step(C.Structure):
         ("joint_mode", _i32),
         ("expert_subset", _i32),
         ("backward", _i32),
+        ("group_rows", _i32),
         ("num_subsets", _i32),
         ("sub_mask", _i32 * MAX_SUBSETS),
         ("sub_avail", _i32 * MAX_SUBSETS),

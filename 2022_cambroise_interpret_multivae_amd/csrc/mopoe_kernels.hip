@@ -156,10 +156,7 @@ DEV void adam_update(const AdamCoef& c, float g, float p, float m, float v, floa
     *po = p - c.step_size * (m1 / denom);                 // addcdiv_(m, denom, -step)
 }
 
-constexpr int kLinThreads = 512;  // 8 waves: 4 column tiles x 2 interleaved K halves
-constexpr int kLinRedFloats = 4 * kWave * 4;
-
-__global__ __launch_bounds__(kLinThreads) void k_linear(const LinArgs a_by_value) {
+__global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
     (void)a_by_value;  // read in place (see k_latent)
     const LinArgs& a = *(const LinArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -180,15 +177,10 @@ __global__ __launch_bounds__(kLinThreads) void k_linear(const LinArgs a_by_value
     if ((int)blockIdx.x * 64 >= g.ncols) return;
     const int K = g.K;
     const rsrc_t xr = make_rsrc_max(g.X);
-    const bool vec = K % 4 == 0;   // 4-wide reads stay inside a row
+    const bool vecx = K % 4 == 0;   // 4-wide reads stay inside a row
+    const bool vecw = K % 4 == 0;
     const int n0 = blockIdx.y * kRows;
-    // The step is a chain of dependent latencies, so a tile's K axis is cut in two
-    // interleaved halves (fragment f of 16 k goes to half f & 1) owned by two
-    // waves, and a wave requests ALL its W fragments of a 512-deep stretch at
-    // once: one round trip to L2/HBM per wave for K <= 512, and an MFMA
-    // accumulation chain half as long.
-    const int tile = wave & 3, kh = wave >> 2;
-    const int j0 = (blockIdx.x * 4 + tile) * 16;
+    const int j0 = (blockIdx.x * 4 + wave) * 16;
 
     // source row of each of the tile's 16 batch rows (gather resolved once)
     __shared__ int rowsel[kRows];
@@ -197,7 +189,7 @@ __global__ __launch_bounds__(kLinThreads) void k_linear(const LinArgs a_by_value
         rowsel[tid] = g.rows ? g.rows[gn] : gn;
     }
     __syncthreads();
-    constexpr int CH = 16;     // W fragments per wave and batch
+    constexpr int CH = 8;     // W fragments per batch (8 x 16 k)
     constexpr int kStage = 4;  // float4 loads in flight per thread while staging
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     for (int kc0 = 0; kc0 < K; kc0 += kEncKChunk) {
@@ -205,30 +197,31 @@ __global__ __launch_bounds__(kLinThreads) void k_linear(const LinArgs a_by_value
         const int Kp = round_up(Kc, 16);
         const int ldx = Kp + 4;
         const int q4 = Kp / 4;
-        const int kend = j0 < g.ncols ? Kp : 0;
-        const rsrc_t wr = make_rsrc(g.W + kc0, (size_t)g.ncols * K * sizeof(float));
-        auto load_w = [&](int i0, f32x4 (&b)[CH]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {  // k >= Kc is out of range -> 0
-                const int kb = 16 * (kh + 2 * (i0 + c));
-                b[c] = vec ? glb_b4_nt<true>(wr, K, Kc, j0, kb, lane)
-                           : glb_b4_nt<false>(wr, K, Kc, j0, kb, lane);
-            }
-        };
+        GemmUnit u;
+        u.As = lds;
+        u.B = g.W + kc0;
+        u.lda = ldx;
+        u.ldb = K;
+        u.ncols = g.ncols;
+        u.K = Kc;
+        u.j0 = j0;
+        u.kbeg = 0;
+        u.kend = j0 < g.ncols ? Kp : 0;
+        u.vec = vecw;
         // the wave's first batch of W fragments is in flight while the
         // workgroup stages the input tile
         f32x4 b[CH];
-        load_w(0, b);
+        load_batch<true, CH>(u, 0, b, lane);
         if (kc0 > 0) __syncthreads();
-        for (int s0 = 0; s0 < kRows * q4; s0 += kStage * kLinThreads) {
+        for (int s0 = 0; s0 < kRows * q4; s0 += kStage * 256) {
             f32x4 v[kStage];
 #pragma unroll
             for (int i = 0; i < kStage; ++i) {
-                const int s = s0 + i * kLinThreads + tid;
+                const int s = s0 + i * 256 + tid;
                 const int r = min(s / q4, kRows - 1), k = (s - (s / q4) * q4) * 4;
                 const bool rv = (s < kRows * q4) & (n0 + r < N);
                 const uint32_t base = (uint32_t)(rowsel[r] * g.ldx + kc0 + k) * 4u;
-                if (vec) {
+                if (vecx) {
                     v[i] = ldg4(xr, guard(base, rv & (k < Kc)));
                 } else {
 #pragma unroll
@@ -238,7 +231,7 @@ __global__ __launch_bounds__(kLinThreads) void k_linear(const LinArgs a_by_value
             }
 #pragma unroll
             for (int i = 0; i < kStage; ++i) {
-                const int s = s0 + i * kLinThreads + tid;
+                const int s = s0 + i * 256 + tid;
                 if (s < kRows * q4) {
                     const int r = s / q4, k = (s - r * q4) * 4;
                     *reinterpret_cast<f32x4*>(lds + r * ldx + k) = v[i];
@@ -246,34 +239,15 @@ __global__ __launch_bounds__(kLinThreads) void k_linear(const LinArgs a_by_value
             }
         }
         __syncthreads();
-        for (int i0 = 0; 16 * (kh + 2 * i0) < kend; i0 += CH) {
+        for (int kb = 0; kb < u.kend; kb += 16 * CH) {
             f32x4 bn[CH];
-            const bool more = 16 * (kh + 2 * (i0 + CH)) < kend;  // wave-uniform
-            if (more) load_w(i0 + CH, bn);
+            load_batch<true, CH>(u, kb + 16 * CH, bn, lane);  // clamped past the end
+            mma_batch<CH>(u, kb, b, acc, acc2, lane);
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const int k = 16 * (kh + 2 * (i0 + c));
-                if (k < kend) {  // wave-uniform
-                    const f32x4 av = lds_a4(lds, ldx, k, lane);
-                    acc = mfma_16x16x4(av[0], b[c][0], acc);
-                    acc2 = mfma_16x16x4(av[1], b[c][1], acc2);
-                    acc = mfma_16x16x4(av[2], b[c][2], acc);
-                    acc2 = mfma_16x16x4(av[3], b[c][3], acc2);
-                }
-            }
-            if (more) {
-#pragma unroll
-                for (int c = 0; c < CH; ++c) b[c] = bn[c];
-            }
+            for (int c = 0; c < CH; ++c) b[c] = bn[c];
         }
     }
     acc += acc2;
-    // the odd K half hands its partial tile over through LDS (behind the x tile)
-    float* red = lds + kRows * (round_up(min(K, kEncKChunk), 16) + 4);
-    if (kh == 1) *reinterpret_cast<f32x4*>(red + (tile * kWave + lane) * 4) = acc;
-    __syncthreads();
-    if (kh == 1) return;
-    acc += *reinterpret_cast<const f32x4*>(red + (tile * kWave + lane) * 4);
     const int col = j0 + (lane & 15);
     if (col >= g.ncols) return;
     const float bias = g.b ? g.b[col] : 0.f;
@@ -293,8 +267,9 @@ __global__ __launch_bounds__(kLinThreads) void k_linear(const LinArgs a_by_value
 // (run_epochs.py:89-128, mm_div.py:92-111, kl_div.py:7-14).  One block of 256
 // threads; one thread per scalar -- a single thread walking the descriptor
 // arrays pays one scalar-memory round trip per element and took ~11 us.
+template <int SLICES>  // = block size / 64
 DEV void finalize_stats(const KArgs& a, int tid) {
-    __shared__ float slab[4][kStatStride];
+    __shared__ float slab[SLICES][kStatStride];
     __shared__ float kld[kStatStride];      // scalar values, by partial index
     __shared__ float contrib[kStatStride];  // their share of total_loss
     __shared__ float jdc[MOPOE_MAX_SUBSETS];
@@ -302,19 +277,32 @@ DEV void finalize_stats(const KArgs& a, int tid) {
     const mopoe_step& st = a.st;
     const int tiles = cdiv(st.n, kRows);
     const int stride = a.lds.part_stride;
-    {   // partial index p = tid % 64, tile slice = tid / 64; slices summed in order
+    {   // partial index p = tid % 64, tile slice = tid / 64; slices summed in order.
+        // Four interleaved accumulators keep four loads in flight per thread (a
+        // 50,000-row forward has 3125 row groups to add up).
         const int p = tid & 63, sl = tid >> 6;
-        const int per = cdiv(tiles, 4);
-        float s = 0.f;
-        if (p < kNumPart)
-            for (int t = sl * per; t < min((sl + 1) * per, tiles); ++t)
-                s += buf.partials[(size_t)t * stride + p];
-        slab[sl][p] = s;
+        const int per = cdiv(tiles, SLICES);
+        const int t1 = min((sl + 1) * per, tiles);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (p < kNumPart) {
+            const float* q = buf.partials + p;
+            int t = sl * per;
+            for (; t + 3 < t1; t += 4) {
+                s0 += q[(size_t)t * stride];
+                s1 += q[(size_t)(t + 1) * stride];
+                s2 += q[(size_t)(t + 2) * stride];
+                s3 += q[(size_t)(t + 3) * stride];
+            }
+            for (; t < t1; ++t) s0 += q[(size_t)t * stride];
+        }
+        slab[sl][p] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     const float fn = (float)st.n;
     if (tid < kNumPart) {
-        const float sum = ((slab[0][tid] + slab[1][tid]) + slab[2][tid]) + slab[3][tid];
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < SLICES; ++k) sum += slab[k][tid];
         float v = 0.f, c = 0.f;
         int out = -1;
         if (tid < kPartKlStyle) {                       // KL of subset s
@@ -601,13 +589,15 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
         return;
     }
     // last block: scalars of the step (run_epochs.py:89-128) + step counter
-    finalize_stats(a, tid);
+    finalize_stats<4>(a, tid);
     if (tid == 0 && a.st.backward) buf.counters[1] += 1;
 }
 
 // forward-only finalisation of the scalars
-__global__ __launch_bounds__(256) void k_finalize(const KArgs a) {
-    finalize_stats(a, threadIdx.x);
+__global__ __launch_bounds__(1024) void k_finalize(const KArgs a_by_value) {
+    (void)a_by_value;  // read in place (see k_latent)
+    const KArgs& a = *(const KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    finalize_stats<16>(a, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -788,6 +778,10 @@ int validate(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* 
         return fail(MOPOE_ERR_ARG, "num_subsets out of range%s");
     if (st->num_comp < 1 || st->num_comp > MOPOE_MAX_SUBSETS)
         return fail(MOPOE_ERR_ARG, "num_comp out of range%s");
+    if (st->group_rows < 0 || (st->group_rows > 0 && st->n % st->group_rows != 0))
+        return fail(MOPOE_ERR_ARG, "group_rows must be 0 or divide n%s");
+    if (st->group_rows > 0 && st->backward)
+        return fail(MOPOE_ERR_ARG, "group_rows is a forward-only feature%s");
     if (st->num_jobs < 1 || st->num_jobs > MOPOE_MAX_JOBS)
         return fail(MOPOE_ERR_ARG, "num_jobs out of range%s");
     for (int s = 0; s < st->num_subsets; ++s) {
@@ -848,11 +842,11 @@ int latent_lds_bytes(const mopoe_model& mdl, const mopoe_step& st) {
 
 int launch_linear(const LinArgs& la, int max_k, int max_cols, hipStream_t s) {
     const int kp = round_up(max_k < kEncKChunk ? max_k : kEncKChunk, 16);
-    const size_t lds = ((size_t)kRows * (kp + 4) + kLinRedFloats) * sizeof(float);
+    const size_t lds = (size_t)kRows * (kp + 4) * sizeof(float);
     {
         ProfScope ps(MOPOE_KERNEL_LINEAR, s);
         hipLaunchKernelGGL(k_linear, dim3(cdiv(max_cols, 64), cdiv(la.n, kRows), la.ngroups),
-                           dim3(kLinThreads), lds, s, la);
+                           dim3(256), lds, s, la);
     }
     return check_launch("k_linear");
 }
@@ -1035,7 +1029,7 @@ int mopoe_forward(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buff
     if (int rc = launch_forward_part(ka, nullptr, s)) return rc;
     {
         ProfScope ps(MOPOE_KERNEL_FINALIZE, s);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, ka);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, ka);
     }
     return check_launch("k_finalize");
 }

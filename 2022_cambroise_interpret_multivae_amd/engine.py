@@ -198,10 +198,12 @@ class MoPoEEngine:
 
     # ----------------------------------------------------------------- calls
     def forward(self, batch, sample=True, use_expert=None, eps=None,
-                row_index=None, loss=False, fresh=True):
-        """mopoe_forward: encoder, fusion, latent, decoder, loss scalars."""
+                row_index=None, loss=False, fresh=True, group_rows=0):
+        """mopoe_forward: encoder, fusion, latent, decoder, loss scalars.
+        `group_rows`: the batch axis holds n/group_rows independent batches."""
         x, n, row_index = self._prepare(batch, row_index)
-        plan = self.spec.plan(list(x.keys()), n, sample, use_expert, False, loss)
+        plan = self.spec.plan(list(x.keys()), n, sample, use_expert, False, loss,
+                              group_rows)
         slots = max(plan.jobs_per_mod)
         ws = self.workspace(n, slots, False, fresh=fresh)
         step = plan.c_step

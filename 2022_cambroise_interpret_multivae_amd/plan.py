@@ -161,11 +161,12 @@ class ModelSpec:
 
     # ------------------------------------------------------------------
     def plan(self, present, n, sample=True, use_expert=None, backward=False,
-             loss=False):
+             loss=False, group_rows=0):
         """`loss`: also run the decoder passes that only the loss needs (the
-        unimodal forwards of method poe, run_epochs.py:104-128)."""
+        unimodal forwards of method poe, run_epochs.py:104-128).  `group_rows`:
+        the n rows are n/group_rows independent batches (mopoe_step.group_rows)."""
         key = (tuple(present), int(n), bool(sample), use_expert, bool(backward),
-               bool(loss or backward))
+               bool(loss or backward), int(group_rows))
         p = self._plans.get(key)
         if p is None:
             p = StepPlan(self, *key)
@@ -185,9 +186,14 @@ def _uniform_slice(n, k):
 class StepPlan:
     """One `mopoe_step` descriptor + the bookkeeping to read results back."""
 
-    def __init__(self, spec, present, n, sample, use_expert, backward, loss):
+    def __init__(self, spec, present, n, sample, use_expert, backward, loss,
+                 group_rows=0):
         self.spec = spec
         self.n = n
+        if group_rows and (n % group_rows or backward):
+            raise ValueError("group_rows must divide n and is forward-only")
+        self.group_rows = group_rows
+        n_sel = group_rows or n     # the batch the row-position rules see
         self.sample = sample
         self.backward = backward
         names = spec.names
@@ -205,6 +211,7 @@ class StepPlan:
         st.present_mask = mask
         st.sample = int(sample)
         st.backward = int(backward)
+        st.group_rows = int(group_rows)
         st.num_subsets = len(spec.subset_keys)
 
         # subsets (BaseMMVae.inference :190-216)
@@ -220,7 +227,7 @@ class StepPlan:
             E = len(members)
             if spec.method == "moe":
                 st.sub_kind[s] = L.SUB_SLICES
-                st.sub_f[s] = _uniform_slice(n, E)[0]
+                st.sub_f[s] = _uniform_slice(n_sel, E)[0]
             elif spec.method == "poe" or E == M:   # BaseMMVae.poe_fusion :110-111
                 st.sub_kind[s] = L.SUB_POE_PRIOR
             else:
@@ -239,7 +246,7 @@ class StepPlan:
         else:
             comp = list(avail_idx)
         K = len(comp)
-        f, w = _uniform_slice(n, K)
+        f, w = _uniform_slice(n_sel, K)
         st.num_comp = K
         st.comp_f = f
         for k, s in enumerate(comp):

@@ -108,6 +108,13 @@ typedef struct mopoe_step {
     int32_t joint_mode;     /* MOPOE_JOINT_*                                   */
     int32_t expert_subset;  /* subset index for MOPOE_JOINT_EXPERT             */
     int32_t backward;       /* also compute gradients (training step)          */
+    int32_t group_rows;     /* 0, or rows per logical batch: the n rows are
+                               n/group_rows independent batches folded into the
+                               batch axis (the repeated forwards of
+                               workflow.py:388-419 as one launch); the
+                               row-position rules (mixture slices, utils.py:63-85;
+                               moe slices) apply to row mod group_rows, and
+                               comp_f / sub_f are sized for group_rows          */
 
     /* non-empty subsets in BaseExperiment.set_subsets order
      * (utils/BaseExperiment.py:58-79) */

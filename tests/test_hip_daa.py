@@ -1,0 +1,96 @@
+"""f2: the repeated forwards of the daa workflow
+(reference workflow.py:388-419) folded into the batch axis -- one launch must give
+exactly what the separate forwards give, and match the oracle run once per repeat."""
+import pytest
+import torch
+
+import mopoe_oracle as mo
+from hip_util import Report, TOL, make_engine
+from surface_util import make_experiment
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(method="joint_elbo"):
+    return mo.Config(["clinical", "rois"], [7, 444], [3, 20], method=method)
+
+
+@pytest.mark.parametrize("method", ["joint_elbo", "moe"])
+def test_folded_repeats_match_the_oracle_per_repeat(method):
+    """n = 20 rows (3 mixture components: slices 6/6/8), 5 repeats with injected eps:
+    every repeat must equal an oracle forward of the 20-row batch with its eps."""
+    cfg = _cfg(method)
+    spec, eng = make_engine(cfg)
+    params = mo.init_params(cfg, 0)
+    n, R = 20, 5
+    g = torch.Generator().manual_seed(3)
+    x = {"clinical": torch.randn(n, 7, generator=g), "rois": torch.randn(n, 444, generator=g)}
+    eps = [torch.randn(R * n, 20, generator=g), torch.randn(R * n, 3, generator=g),
+           torch.randn(R * n, 20, generator=g)]
+    idx = torch.arange(n, dtype=torch.int32).repeat(R)
+    plan, ws = eng.forward({k: v.cuda() for k, v in x.items()}, sample=True, eps=eps,
+                           row_index=idx.cuda(), group_rows=n)
+    torch.cuda.synchronize()
+    rep = Report("folded repeats vs oracle, " + method)
+    rt, at = TOL["loc"]
+    lt, la = TOL["latent"]
+    for r in range(R):
+        tape = [e[r * n:(r + 1) * n] for e in eps]
+        out = mo.forward(params, cfg, x, mo.Noise(tape=tape), sample_latents=True)
+        sl = slice(r * n, (r + 1) * n)
+        rep.close("rep%d/joint_mu" % r, ws.joint_mu[sl], out["latents"]["joint"][0], lt, la)
+        rep.close("rep%d/joint_lv" % r, ws.joint_logvar[sl], out["latents"]["joint"][1], lt, la)
+        for m, name in enumerate(cfg.names):
+            rep.close("rep%d/loc/%s" % (r, name), ws.loc[m][sl], out["rec"][name][0], rt, at)
+    rep.finish()
+
+
+def test_daa_helpers_equal_the_separate_forwards():
+    """sample_latents=False makes the forwards deterministic: the folded launch must
+    reproduce, bit for bit, the loop of separate forwards the reference runs."""
+    from importlib import import_module
+    daa = import_module("2022_cambroise_interpret_multivae_amd.daa")
+    exp = make_experiment(_cfg(), "cuda")
+    model = exp.models
+    model.load_state_dict(mo.init_params(_cfg(), 0))
+    n, n_samples = 12, 4
+    g = torch.Generator().manual_seed(5)
+    data = {"clinical": torch.randn(n, 7, generator=g).cuda(),
+            "rois": torch.randn(n, 444, generator=g).cuda()}
+    rec = daa.repeated_reconstructions(model, data, 6, sample_latents=False)
+    one = model(data, sample_latents=False)["rec"]
+    for name in data:
+        loc, scale = rec[name]
+        assert loc.shape == (6, n, data[name].shape[1])
+        for i in range(6):
+            assert torch.equal(loc[i], one[name].loc), name
+        assert torch.equal(scale.expand_as(one[name].loc), one[name].scale.expand_as(one[name].loc))
+    # stochastic repeats differ from one another and average towards the mean path
+    st = daa.repeated_reconstructions(model, data, 64, sample_latents=True)["rois"][0]
+    assert not torch.equal(st[0], st[1])
+    mean = daa.mean_reconstructions(model, data, 64)["rois"][0]   # (a fresh draw)
+    assert mean.shape == (n, 444) and bool(torch.isfinite(mean).all())
+
+    for strategy in ("likelihood", "linear"):
+        shape = (n_samples, n, 7) if strategy == "likelihood" else (n, n_samples, 7)
+        sv = torch.randn(*shape, generator=g).cuda()
+        got = daa.perturbed_reconstructions(model, data, sv, strategy, sample_latents=False)
+        assert got.shape == (n, 7, n_samples, 444)
+        for sample_idx in range(n_samples):      # workflow.py:405-419, verbatim loop shape
+            for idx in range(7):
+                cdata = data["clinical"].clone()
+                if strategy == "likelihood":
+                    cdata[:, idx] = sv[sample_idx, :, idx]
+                else:
+                    cdata[:, idx] = sv[:, sample_idx, idx]
+                want = model({"clinical": cdata, "rois": data["rois"]},
+                             sample_latents=False)["rec"]["rois"].loc
+                assert torch.equal(got[:, idx, sample_idx], want), (strategy, sample_idx, idx)
+
+
+def test_group_rows_is_validated():
+    cfg = _cfg()
+    spec, eng = make_engine(cfg)
+    x = {"clinical": torch.zeros(20, 7).cuda(), "rois": torch.zeros(20, 444).cuda()}
+    with pytest.raises(ValueError):
+        eng.forward(x, group_rows=7)

@@ -120,3 +120,23 @@ def test_plan_reproduces_reference_mixture_and_subsets(case):
         assert starts[k] <= n < ends[k]
     assert abs(sum(plan.comp_w) - 1.0) < 1e-6
     assert plan.lds_bytes() <= 160 * 1024
+
+
+def test_group_rows_sizes_the_row_position_rules_for_one_repeat():
+    """f2: with group_rows the mixture / moe slice sizes are those of ONE repeat
+    (the batch mixture_component_selection sees in the reference's separate
+    forwards, utils/utils.py:63-85), not of the folded batch."""
+    spec = mm.ModelSpec(["clinical", "rois"], [7, 444], [3, 20], method="joint_elbo")
+    names = ["clinical", "rois"]
+    one = spec.plan(names, 50)
+    folded = spec.plan(names, 50 * 40, group_rows=50)
+    assert folded.c_step.group_rows == 50 and folded.c_step.n == 2000
+    assert folded.c_step.comp_f == one.c_step.comp_f == 16   # floor(50/3)
+    assert spec.plan(names, 2000).c_step.comp_f == 666
+    moe = mm.ModelSpec(names, [7, 444], [3, 20], method="moe")
+    a, b = moe.plan(names, 50), moe.plan(names, 500, group_rows=50)
+    assert list(a.c_step.sub_f) == list(b.c_step.sub_f)
+    with pytest.raises(ValueError):
+        spec.plan(names, 2000, group_rows=30)          # must divide n
+    with pytest.raises(ValueError):
+        spec.plan(names, 2000, backward=True, group_rows=50)   # forward-only
