@@ -73,6 +73,18 @@ constexpr float kPoeEps = 1e-8f;
     do {                          \
     } while (0)
 #endif
+// whole-step timeline (diagnostic build): 100 MHz realtime counter words written
+// straight to global memory by one thread of one block
+#ifdef MOPOE_STAMPS
+#define GSTAMP(ptr, i, cond)                                                            \
+    do {                                                                               \
+        if (cond) ((volatile unsigned*)(ptr))[i] = (unsigned)__builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define GSTAMP(ptr, i, cond) \
+    do {                     \
+    } while (0)
+#endif
 #define STOP_AFTER(buf, i) \
     do {                   \
     } while (0)
@@ -112,6 +124,7 @@ struct LinArgs {
     int32_t ngroups;
     int32_t* counters;     // training step: bump [0], publish Adam coefficients
     int32_t publish;       // adam is valid: publish its step coefficients
+    int32_t ksplit;        // 1, 2 or 4: K parts per column tile (set by launch_linear)
     mopoe_adam adam;
     LinGroup g[MOPOE_MAX_MODS];
 };
@@ -146,6 +159,31 @@ DEV AdamCoef adam_coef_load(const int32_t* counters, const mopoe_adam& ad) {
     return *reinterpret_cast<const AdamCoef*>(counters + kCoefBase);
 }
 
+// The same in two halves, so that the loads go out beside a block's other operand
+// loads and the branch on their values sits where the data is first needed (a
+// branch right after the request would hold every later load back one round trip).
+struct AdamCoefRaw {
+    int t, tag;
+    AdamCoef c;
+};
+DEV AdamCoefRaw adam_coef_request(const int32_t* counters) {
+    AdamCoefRaw r;
+    r.t = __builtin_nontemporal_load(counters);
+    r.tag = __builtin_nontemporal_load(counters + kCoefTag);
+    const float* f = reinterpret_cast<const float*>(counters + kCoefBase);
+    r.c.b2 = __builtin_nontemporal_load(f + 0);
+    r.c.one_m_b1 = __builtin_nontemporal_load(f + 1);
+    r.c.one_m_b2 = __builtin_nontemporal_load(f + 2);
+    r.c.step_size = __builtin_nontemporal_load(f + 3);
+    r.c.bc2_sqrt = __builtin_nontemporal_load(f + 4);
+    r.c.eps = __builtin_nontemporal_load(f + 5);
+    r.c.pad = 0.f;
+    return r;
+}
+DEV AdamCoef adam_coef_resolve(const AdamCoefRaw& r, const mopoe_adam& ad) {
+    return r.tag == r.t ? r.c : adam_coef(ad, r.t);
+}
+
 DEV void adam_update(const AdamCoef& c, float g, float p, float m, float v, float* po,
                      float* mo, float* vo) {
     const float m1 = m + c.one_m_b1 * (g - m);           // exp_avg.lerp_(g, 1-b1)
@@ -156,62 +194,46 @@ DEV void adam_update(const AdamCoef& c, float g, float p, float m, float v, floa
     *po = p - c.step_size * (m1 / denom);                 // addcdiv_(m, denom, -step)
 }
 
-__global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
-    (void)a_by_value;  // read in place (see k_latent)
-    const LinArgs& a = *(const LinArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    // wave id as a provably wave-uniform scalar (guide T20): everything derived
-    // from it stays in SGPRs and buffer descriptors need no waterfall loop
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = a.n;
-    if (a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
-        const int t = a.counters[0] + 1;  // training step number (Adam, Philox)
-        a.counters[0] = t;
-        if (a.publish) {
-            *reinterpret_cast<AdamCoef*>(a.counters + kCoefBase) = adam_coef(a.adam, t);
-            a.counters[kCoefTag] = t;
-        }
-    }
-    const LinGroup& g = a.g[blockIdx.z];
-    if ((int)blockIdx.x * 64 >= g.ncols) return;
-    const int K = g.K;
-    const rsrc_t xr = make_rsrc_max(g.X);
-    const bool vecx = K % 4 == 0;   // 4-wide reads stay inside a row
-    const bool vecw = K % 4 == 0;
-    const int n0 = blockIdx.y * kRows;
-    const int j0 = (blockIdx.x * 4 + wave) * 16;
+constexpr int kLinRedFloats = 4 * kWave * 4;  // partial tiles handed over through LDS
 
-    // source row of each of the tile's 16 batch rows (gather resolved once)
-    __shared__ int rowsel[kRows];
-    if (tid < kRows) {
-        const int gn = min(n0 + tid, N - 1);
-        rowsel[tid] = g.rows ? g.rows[gn] : gn;
-    }
-    __syncthreads();
-    constexpr int CH = 8;     // W fragments per batch (8 x 16 k)
-    constexpr int kStage = 4;  // float4 loads in flight per thread while staging
+// One workgroup = 4 waves = one 16-row tile x (4 / KS) column tiles of 16, the K axis
+// of a column tile cut in KS interleaved parts (fragment f of 16 k belongs to part
+// f % KS), one wave per (column tile, part).  KS = 4 for small batches: the MFMA
+// accumulation chain of a 16x16 tile over K = 444 is 111 issues of 32 cycles, and a
+// small batch has too few tiles to keep the chip's SIMDs busy otherwise; KS = 1 for
+// large ones, where a workgroup should cover as many columns per staged x tile as it can.
+template <int KS>
+DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int* rowsel,
+                     int tid, int lane, int wave) {
+    constexpr int CH = 8;      // W fragments per wave and batch
+    constexpr int kStage = 8;  // float4 loads in flight per thread while staging
+    const int N = a.n, K = g.K;
+    const bool vec = K % 4 == 0;   // 4-wide reads stay inside a row
+    const int n0 = blockIdx.y * kRows;
+    const int tile = wave / KS, part = wave % KS;
+    const int j0 = (blockIdx.x * (4 / KS) + tile) * 16;
+    const rsrc_t xr = make_rsrc_max(g.X);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     for (int kc0 = 0; kc0 < K; kc0 += kEncKChunk) {
         const int Kc = min(kEncKChunk, K - kc0);
         const int Kp = round_up(Kc, 16);
         const int ldx = Kp + 4;
         const int q4 = Kp / 4;
-        GemmUnit u;
-        u.As = lds;
-        u.B = g.W + kc0;
-        u.lda = ldx;
-        u.ldb = K;
-        u.ncols = g.ncols;
-        u.K = Kc;
-        u.j0 = j0;
-        u.kbeg = 0;
-        u.kend = j0 < g.ncols ? Kp : 0;
-        u.vec = vecw;
-        // the wave's first batch of W fragments is in flight while the
-        // workgroup stages the input tile
+        const int kend = j0 < g.ncols ? Kp : 0;
+        const rsrc_t wr = make_rsrc(g.W + kc0, (size_t)g.ncols * K * sizeof(float));
+        // fragment i of this wave starts at k = 16 * (part + KS * i)
+        auto load_w = [&](int i0, f32x4 (&b)[CH]) __attribute__((always_inline)) {
+            if (vec) {  // (a select of the two forms would issue BOTH sets of loads)
+#pragma unroll
+                for (int c = 0; c < CH; ++c)  // k >= Kc is out of range -> 0
+                    b[c] = glb_b4_nt<true>(wr, K, Kc, j0, 16 * (part + KS * (i0 + c)), lane);
+            } else {
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    b[c] = glb_b4_nt<false>(wr, K, Kc, j0, 16 * (part + KS * (i0 + c)), lane);
+            }
+        };
         f32x4 b[CH];
-        load_batch<true, CH>(u, 0, b, lane);
         if (kc0 > 0) __syncthreads();
         for (int s0 = 0; s0 < kRows * q4; s0 += kStage * 256) {
             f32x4 v[kStage];
@@ -220,8 +242,9 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
                 const int s = s0 + i * 256 + tid;
                 const int r = min(s / q4, kRows - 1), k = (s - (s / q4) * q4) * 4;
                 const bool rv = (s < kRows * q4) & (n0 + r < N);
-                const uint32_t base = (uint32_t)(rowsel[r] * g.ldx + kc0 + k) * 4u;
-                if (vecx) {
+                const int row = rowsel ? rowsel[r] : min(n0 + r, N - 1);
+                const uint32_t base = (uint32_t)(row * g.ldx + kc0 + k) * 4u;
+                if (vec) {
                     v[i] = ldg4(xr, guard(base, rv & (k < Kc)));
                 } else {
 #pragma unroll
@@ -229,6 +252,10 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
                         v[i][e] = ldg(xr, guard(base + 4u * e, rv & (k + e < Kc)));
                 }
             }
+            // the wave's first batch of W fragments goes out BEHIND the x loads (loads
+            // return in order: requested first, it would hold the x tile -- and the
+            // barrier every wave waits at -- back until W has arrived too)
+            if (s0 == 0) load_w(0, b);
 #pragma unroll
             for (int i = 0; i < kStage; ++i) {
                 const int s = s0 + i * 256 + tid;
@@ -239,15 +266,44 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
             }
         }
         __syncthreads();
-        for (int kb = 0; kb < u.kend; kb += 16 * CH) {
+        GSTAMP(a.counters, 14, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
+        for (int i0 = 0; 16 * (part + KS * i0) < kend; i0 += CH) {
             f32x4 bn[CH];
-            load_batch<true, CH>(u, kb + 16 * CH, bn, lane);  // clamped past the end
-            mma_batch<CH>(u, kb, b, acc, acc2, lane);
+            const bool more = 16 * (part + KS * (i0 + CH)) < kend;  // wave-uniform
+            if (more) load_w(i0 + CH, bn);
+            // No branch per fragment: it would put every LDS read behind the previous
+            // fragment's MFMAs.  A fragment past the end of K multiplies the (finite)
+            // first fragment of the x tile by W values read out of range, i.e. zeros.
+            f32x4 av[CH];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) b[c] = bn[c];
+            for (int c = 0; c < CH; ++c) {
+                const int k = 16 * (part + KS * (i0 + c));
+                av[c] = lds_a4(lds, ldx, k < kend ? k : 0, lane);
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                acc = mfma_16x16x4(av[c][0], b[c][0], acc);
+                acc2 = mfma_16x16x4(av[c][1], b[c][1], acc2);
+                acc = mfma_16x16x4(av[c][2], b[c][2], acc);
+                acc2 = mfma_16x16x4(av[c][3], b[c][3], acc2);
+            }
+            if (more) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) b[c] = bn[c];
+            }
         }
     }
     acc += acc2;
+    GSTAMP(a.counters, 15, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
+    if (KS > 1) {  // parts 1.. hand their partial tiles over through LDS (behind the x tile)
+        float* red = lds + kRows * (round_up(min(K, kEncKChunk), 16) + 4);
+        if (part > 0) *reinterpret_cast<f32x4*>(red + ((wave - 1) * kWave + lane) * 4) = acc;
+        __syncthreads();
+        if (part > 0) return;
+#pragma unroll
+        for (int p = 1; p < KS; ++p)  // fixed order
+            acc += *reinterpret_cast<const f32x4*>(red + ((wave + p - 1) * kWave + lane) * 4);
+    }
     const int col = j0 + (lane & 15);
     if (col >= g.ncols) return;
     const float bias = g.b ? g.b[col] : 0.f;
@@ -259,6 +315,44 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
             g.Y[(size_t)gn * g.ldy + col] = g.relu ? fmaxf(v, 0.f) : v;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
+    (void)a_by_value;  // read in place (see k_latent)
+    const LinArgs& a = *(const LinArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave id as a provably wave-uniform scalar (guide T20): everything derived
+    // from it stays in SGPRs and buffer descriptors need no waterfall loop
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    GSTAMP(a.counters, 11, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
+    if (a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+        const int t = a.counters[0] + 1;  // training step number (Adam, Philox)
+        a.counters[0] = t;
+        if (a.publish) {
+            *reinterpret_cast<AdamCoef*>(a.counters + kCoefBase) = adam_coef(a.adam, t);
+            a.counters[kCoefTag] = t;
+        }
+    }
+    const LinGroup& g = a.g[blockIdx.z];
+    const int ks = a.ksplit;
+    if ((int)blockIdx.x * (64 / ks) >= g.ncols) return;
+    // source row of each of the tile's 16 batch rows (a gather is resolved once)
+    __shared__ int rowsel[kRows];
+    const bool gather = g.rows != nullptr;
+    if (gather) {
+        if (tid < kRows) rowsel[tid] = g.rows[min((int)blockIdx.y * kRows + tid, a.n - 1)];
+        __syncthreads();
+    }
+    GSTAMP(a.counters, 13, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
+    const int* rs = gather ? rowsel : nullptr;
+    if (ks == 4)
+        linear_tile<4>(a, g, lds, rs, tid, lane, wave);
+    else if (ks == 2)
+        linear_tile<2>(a, g, lds, rs, tid, lane, wave);
+    else
+        linear_tile<1>(a, g, lds, rs, tid, lane, wave);
+    GSTAMP(a.counters, 12, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
 }
 
 #include "mopoe_latent.inc"
@@ -447,6 +541,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform (T20)
     const int b = blockIdx.x;
     const bool fuse = w.fuse_adam != 0;
+    const bool stamp_blk = b == 20 && tid == 0;  // a W1 block of the large modality
+    (void)stamp_blk;
+    GSTAMP(buf.stats, 64 + 40, stamp_blk);
 
     if (b < w.total_tiles) {
         // job of this block: compares against one contiguous table (a scan over
@@ -473,9 +570,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
         // (16-byte reads; elements past the row end are neighbours, never written back)
         f32x4 pp = {0.f, 0.f, 0.f, 0.f}, pm = pp, pv = pp;
         float bp = 0.f, bm = 0.f, bv = 0.f;
-        AdamCoef ac;
+        AdamCoefRaw acr;
         if (fuse) {
-            ac = adam_coef_load(buf.counters, w.adam);
+            acr = adam_coef_request(buf.counters);
             const uint32_t o = guard((uint32_t)widx * 4u, nvalid > 0);
             pp = ldg4(rp, o);
             pm = ldg4(rm, o);
@@ -486,6 +583,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
             bv = ldg(rv, ob);
         }
 
+        GSTAMP(buf.stats, 64 + 41, stamp_blk);
         const int rq = round_up(cdiv(R, 4), 4);
         const int rbeg = wave * rq, rend = min(rbeg + rq, R);
         const rsrc_t gr = make_rsrc(job.G, (size_t)R * job.ldg * sizeof(float));
@@ -498,6 +596,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
         else
             wgrad_rows<false>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0, rbeg, rend,
                               lane, acc);
+        GSTAMP(buf.stats, 64 + 42, stamp_blk);
         // this wave's partial block -> LDS as [i][j]
         {
             const int c = lane & 15, q = lane >> 4;
@@ -516,6 +615,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
         g += *reinterpret_cast<const f32x4*>(&blk[1][li * kWgLd + lj]);
         g += *reinterpret_cast<const f32x4*>(&blk[2][li * kWgLd + lj]);
         g += *reinterpret_cast<const f32x4*>(&blk[3][li * kWgLd + lj]);
+        GSTAMP(buf.stats, 64 + 43, stamp_blk);
+        AdamCoef ac;
+        if (fuse) ac = adam_coef_resolve(acr, w.adam);
         if (nvalid > 0) {
             f32x4 np = pp, nm = pm, nv = pv;
             if (fuse) {
@@ -554,6 +656,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
                 adam_update(ac, gb, bp, bm, bv, buf.params + bidx, buf.exp_avg + bidx,
                             buf.exp_avg_sq + bidx);
         }
+        GSTAMP(buf.stats, 64 + 44, stamp_blk);
         return;
     }
     AdamCoef ac;
@@ -840,12 +943,18 @@ int latent_lds_bytes(const mopoe_model& mdl, const mopoe_step& st) {
     return L.total * (int)sizeof(float);
 }
 
-int launch_linear(const LinArgs& la, int max_k, int max_cols, hipStream_t s) {
+int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s) {
+    LinArgs la = la_in;
     const int kp = round_up(max_k < kEncKChunk ? max_k : kEncKChunk, 16);
-    const size_t lds = (size_t)kRows * (kp + 4) * sizeof(float);
+    const size_t lds = ((size_t)kRows * (kp + 4) + kLinRedFloats) * sizeof(float);
+    // K parts per column tile: as many as it takes to put ~2 workgroups on every CU
+    const int tiles = cdiv(la.n, kRows) * la.ngroups;
+    int ks = 1;
+    while (ks < 4 && tiles * cdiv(max_cols, 64 / ks) < 2 * 256) ks *= 2;
+    la.ksplit = ks;
     {
         ProfScope ps(MOPOE_KERNEL_LINEAR, s);
-        hipLaunchKernelGGL(k_linear, dim3(cdiv(max_cols, 64), cdiv(la.n, kRows), la.ngroups),
+        hipLaunchKernelGGL(k_linear, dim3(cdiv(max_cols, 64 / ks), cdiv(la.n, kRows), la.ngroups),
                            dim3(256), lds, s, la);
     }
     return check_launch("k_linear");
