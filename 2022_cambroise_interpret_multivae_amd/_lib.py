@@ -58,6 +58,7 @@ class Step(C.Structure):
         ("joint_mode", _i32),
         ("expert_subset", _i32),
         ("backward", _i32),
+        ("rows_per_group", _i32),
         ("group_rows", _i32),
         ("num_subsets", _i32),
         ("sub_mask", _i32 * MAX_SUBSETS),
@@ -126,6 +127,7 @@ SYMBOLS = {
     "mopoe_model_layout": (C.c_int, [C.POINTER(Model)]),
     "mopoe_ldz": (C.c_int, [C.POINTER(Model), C.c_int]),
     "mopoe_partials_stride": (C.c_int, [C.POINTER(Model)]),
+    "mopoe_row_groups": (C.c_int, [C.POINTER(Model), C.POINTER(Step)]),
     "mopoe_latent_lds_bytes": (C.c_int, [C.POINTER(Model), C.POINTER(Step)]),
     "mopoe_forward": (C.c_int, [C.POINTER(Model), C.POINTER(Step),
                                 C.POINTER(Buffers), _ptr]),
@@ -184,6 +186,13 @@ def check(rc, what):
     if rc != 0:
         raise MopoeError("%s failed (%d): %s" % (
             what, rc, lib.mopoe_last_error().decode("utf-8", "replace")))
+
+
+def rows_per_group():
+    """Step.rows_per_group the plans are built with: 0 (the library picks) unless
+    MOPOE_ROWS_PER_GROUP pins it (a test / tuning knob; results do not depend on it
+    beyond the summation order of the scalar partials)."""
+    return int(os.environ.get("MOPOE_ROWS_PER_GROUP", "0"))
 
 
 def require_gpu(t=None):

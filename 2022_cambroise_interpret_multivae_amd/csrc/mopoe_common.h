@@ -91,12 +91,20 @@ struct LatentLds {
     int pass_end[MOPOE_MAX_JOBS];      // one past the last job of the pass starting here
     int pres_mod[MOPOE_MAX_MODS];      // k-th present modality
     int npres;
+    int rows;                          // batch rows a group owns (16, 8, 4, 2 or 1)
+    int rd;                            // round_up(rows * class_dim, 4): stride of a KL-term slab
+    int fits;                          // the carve-up fits the 160 KiB budget
 };
 
-HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
-                          LatentLds& L) {
+// Carve-up for groups of R rows (every tile R rows tall); returns false when even the
+// most frugal option does not fit the 160 KiB budget.
+HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int waves, int R,
+                               LatentLds& L) {
     const int D = m.class_dim;
-    int hsz = 0, xsz = 0, zcols = 0, klt = st.num_subsets * kRows * D;
+    const int RD = round_up(R * D, 4);  // element-wise arrays keep the tiles 16-byte aligned
+    L.rows = R;
+    L.rd = RD;
+    int hsz = 0, xsz = 0, zcols = 0, klt = st.num_subsets * RD;
     int jobs_of[MOPOE_MAX_MODS] = {0, 0, 0, 0, 0};
     for (int j = 0; j < st.num_jobs; ++j) jobs_of[st.job_mod[j]]++;
     for (int i = 0; i < m.num_mods; ++i) {
@@ -104,10 +112,10 @@ HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
         L.xs[i] = xsz;
         L.klt_style[i] = klt;
         if ((st.present_mask >> i) & 1) {
-            hsz += kRows * kLdH;
-            xsz += kRows * ld_x_lds(m, i);
+            hsz += R * kLdH;
+            xsz += R * ld_x_lds(m, i);
             zcols += round_up(z_dim(m, i), 16);
-            klt += kRows * m.style_dim[i];
+            klt += round_up(R * m.style_dim[i], 4);
         }
     }
     L.ld_gzp = zcols + 4;
@@ -123,6 +131,7 @@ HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
     // round trip later) and the largest K-split; fall back until the kernel fits
     // the 160 KiB LDS budget.
     const int klt_rel = klt;
+    bool fits = false;
     int xrel[MOPOE_MAX_MODS];
     for (int i = 0; i < MOPOE_MAX_MODS; ++i) xrel[i] = i < m.num_mods ? L.xs[i] : 0;
     for (int option = 0;; ++option) {
@@ -130,7 +139,7 @@ HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
         const int chunks_of[6] = {8, 4, 8, 4, 2, 1};
         L.xs_early = early_of[option];
         L.gz_chunks = chunks_of[option];
-        int gz = L.gz_chunks * kRows * L.ld_gzp;
+        int gz = L.gz_chunks * R * L.ld_gzp;
         if (gz < klt_rel) gz = klt_rel;
         int off;
         if (L.xs_early) {  // [hs | ...] and [gzp/klt] share R0, xs follows
@@ -145,10 +154,10 @@ HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
         }
         L.klt = L.gzp;
         {
-            int ks = st.num_subsets * kRows * D;
+            int ks = st.num_subsets * RD;
             for (int i = 0; i < m.num_mods; ++i) {
                 L.klt_style[i] = L.klt + ks;
-                if ((st.present_mask >> i) & 1) ks += kRows * m.style_dim[i];
+                if ((st.present_mask >> i) & 1) ks += round_up(R * m.style_dim[i], 4);
             }
         }
         for (int i = 0; i < m.num_mods; ++i) {
@@ -157,40 +166,41 @@ HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
             if (!((st.present_mask >> i) & 1)) continue;
             if (jobs_of[i] > 1) {
                 L.gx[i] = off;
-                off += kRows * ld_x_lds(m, i);
+                off += R * ld_x_lds(m, i);
             }
             L.heads[i] = off;
-            off += kRows * ld_heads_lds(m, i);
+            off += R * ld_heads_lds(m, i);
             L.gheads[i] = off;
-            off += kRows * ld_heads_lds(m, i);
+            off += R * ld_heads_lds(m, i);
             L.tm[i] = off;
-            off += kRows * D;
+            off += RD;
             L.ev[i] = off;
-            off += kRows * D;
+            off += RD;
         }
         for (int j = 0; j < st.num_jobs; ++j) {
             const int i = st.job_mod[j];
             L.zj[j] = off;
-            off += kRows * ld_z_lds(m, i);
+            off += R * ld_z_lds(m, i);
             L.gzj[j] = off;
-            off += kRows * ld_z_lds(m, i);
+            off += R * ld_z_lds(m, i);
             L.epsc[j] = off;
-            off += kRows * D;
+            off += RD;
             L.stdc[j] = off;
-            off += kRows * D;
+            off += RD;
             L.epss[j] = off;
-            off += kRows * m.style_dim[i];
+            off += round_up(R * m.style_dim[i], 4);
             L.stds[j] = off;
-            off += kRows * m.style_dim[i];
+            off += round_up(R * m.style_dim[i], 4);
         }
         off = round_up(off, 4);
         L.red = off;
         off += waves * kStatStride;
         L.total = off;
-        if (off * 4 <= 160 * 1024 || option == 5) break;
+        fits = off * 4 <= 160 * 1024;
+        if (fits || option == 5) break;
     }
     {
-        int t = 0, sl = cdiv(kRows * D, kWave);
+        int t = 0, sl = cdiv(R * D, kWave);
         L.npres = 0;
         for (int i = 0; i < MOPOE_MAX_MODS; ++i) {
             L.s1_begin[i] = t;
@@ -198,7 +208,7 @@ HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
             L.pres_mod[i] = 0;
             if (i < m.num_mods && ((st.present_mask >> i) & 1)) {
                 t += cdiv(heads_dim(m, i), 16);
-                sl += cdiv(kRows * m.style_dim[i], kWave);
+                sl += cdiv(R * m.style_dim[i], kWave);
             }
         }
         for (int i = 0; i < m.num_mods; ++i)
@@ -220,6 +230,30 @@ HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
             L.pass_end[j] = j < st.num_jobs ? je : j + 1;
         }
     }
+    return fits;
+}
+
+
+// Rows per k_latent group: 16 (one full MFMA tile) whenever the carve-up fits the LDS,
+// else the largest of 8, 4, 2, 1 that does (wide inputs, five modalities: the MFMA
+// tiles then run partly empty, which costs nothing -- no stage is MFMA-bound).
+// mopoe_step.rows_per_group pins it (tests exercise the small-group path that way).
+HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
+                          LatentLds& L) {
+    const int r0 = st.rows_per_group;
+    if (r0 == 1 || r0 == 2 || r0 == 4 || r0 == 8 || r0 == 16) {
+        L.fits = latent_lds_layout_rows(m, st, waves, r0, L);
+        return;
+    }
+    for (int R = kRows; R >= 1; R /= 2) {
+        L.fits = latent_lds_layout_rows(m, st, waves, R, L);
+        if (L.fits) return;
+    }
+}
+HD int latent_groups(const mopoe_model& m, const mopoe_step& st, int waves) {
+    LatentLds L;
+    latent_lds_layout(m, st, waves, L);
+    return cdiv(st.n, L.rows);
 }
 
 // ---------------------------------------------------------------------------

@@ -369,7 +369,7 @@ DEV void finalize_stats(const KArgs& a, int tid) {
     __shared__ float jdc[MOPOE_MAX_SUBSETS];
     const mopoe_buffers& buf = a.buf;
     const mopoe_step& st = a.st;
-    const int tiles = cdiv(st.n, kRows);
+    const int tiles = cdiv(st.n, a.lds.rows);
     const int stride = a.lds.part_stride;
     {   // partial index p = tid % 64, tile slice = tid / 64; slices summed in order.
         // Four interleaved accumulators keep four loads in flight per thread (a
@@ -663,21 +663,40 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
     if (fuse) ac = adam_coef_load(buf.counters, w.adam);
     const int lb = b - w.total_tiles;
     if (lb < w.lvo_blocks) {
-        const int tiles = cdiv(a.st.n, kRows);
+        const int tiles = cdiv(a.st.n, a.lds.rows);
         const int stride = a.lds.part_stride;
-        // d loss / d decoders.<m>.logvar: sum of the row tiles' partials
+        // d loss / d decoders.<m>.logvar: sum of the row groups' partials.  A block
+        // owns 64 columns; its four waves take a quarter of the groups each (four
+        // loads in flight per thread) and are added in fixed order through LDS.
         int m = 0;
         while (lb >= w.lvo_block_begin[m + 1]) ++m;
-        const int col = (lb - w.lvo_block_begin[m]) * 256 + tid;
-        if (col < a.mdl.input_dim[m]) {
-            float g = 0.f;
+        const int col = (lb - w.lvo_block_begin[m]) * 64 + lane;
+        const bool on = col < a.mdl.input_dim[m];
+        float g = 0.f;
+        if (on) {
             int slots = 0;
             for (int j = 0; j < a.st.num_jobs; ++j) slots += a.st.job_mod[j] == m;
+            const int per = cdiv(tiles, 4);
+            const int t0 = wave * per, t1 = min(t0 + per, tiles);
             for (int sl = 0; sl < slots; ++sl) {
                 const float* p = buf.partials + a.lds.lvo_off[m] +
                                  sl * lvo_slot_stride(a.mdl, m) + col;
-                for (int t = 0; t < tiles; ++t) g += p[(size_t)t * stride];
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int t = t0;
+                for (; t + 3 < t1; t += 4) {
+                    s0 += p[(size_t)t * stride];
+                    s1 += p[(size_t)(t + 1) * stride];
+                    s2 += p[(size_t)(t + 2) * stride];
+                    s3 += p[(size_t)(t + 3) * stride];
+                }
+                for (; t < t1; ++t) s0 += p[(size_t)t * stride];
+                g += (s0 + s1) + (s2 + s3);
             }
+        }
+        blk[0][wave * 64 + lane] = g;
+        __syncthreads();
+        if (on && wave == 0) {
+            g = ((blk[0][lane] + blk[0][64 + lane]) + blk[0][128 + lane]) + blk[0][192 + lane];
             const int idx = a.mdl.off_lvo[m] + col;
             if (a.mdl.learn_output_scale) {
                 buf.grads[idx] = g;
@@ -885,6 +904,11 @@ int validate(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* 
         return fail(MOPOE_ERR_ARG, "group_rows must be 0 or divide n%s");
     if (st->group_rows > 0 && st->backward)
         return fail(MOPOE_ERR_ARG, "group_rows is a forward-only feature%s");
+    {
+        const int r = st->rows_per_group;
+        if (r != 0 && r != 1 && r != 2 && r != 4 && r != 8 && r != 16)
+            return fail(MOPOE_ERR_ARG, "rows_per_group must be 0, 1, 2, 4, 8 or 16%s");
+    }
     if (st->num_jobs < 1 || st->num_jobs > MOPOE_MAX_JOBS)
         return fail(MOPOE_ERR_ARG, "num_jobs out of range%s");
     for (int s = 0; s < st->num_subsets; ++s) {
@@ -962,7 +986,6 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s) 
 
 int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) {
     const mopoe_model& mdl = ka.mdl;
-    const int tiles = cdiv(ka.st.n, kRows);
     LinArgs la;
     memset(&la, 0, sizeof(la));
     la.n = ka.st.n;
@@ -1000,7 +1023,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     }
     {
         ProfScope ps(MOPOE_KERNEL_LATENT, s);
-        hipLaunchKernelGGL(k_latent, dim3(tiles), dim3(kLatentThreads), (size_t)lds, s, ka);
+        hipLaunchKernelGGL(k_latent, dim3(cdiv(ka.st.n, ka.lds.rows)), dim3(kLatentThreads), (size_t)lds, s, ka);
     }
     return check_launch("k_latent");
 }
@@ -1036,7 +1059,7 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w) {
     int lb = 0;
     for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
         w.lvo_block_begin[m] = lb;
-        if (m < mdl.num_mods && ((st.present_mask >> m) & 1)) lb += cdiv(mdl.input_dim[m], 256);
+        if (m < mdl.num_mods && ((st.present_mask >> m) & 1)) lb += cdiv(mdl.input_dim[m], 64);
     }
     w.lvo_block_begin[MOPOE_MAX_MODS] = lb;
     w.lvo_blocks = lb;
@@ -1120,6 +1143,9 @@ int mopoe_sizeof(int which) {
 int mopoe_ldz(const mopoe_model* mdl, int mod) { return ldz_glb(*mdl, mod); }
 
 int mopoe_partials_stride(const mopoe_model* mdl) { return partials_stride(*mdl); }
+int mopoe_row_groups(const mopoe_model* mdl, const mopoe_step* st) {
+    return mdl && st && st->n > 0 ? latent_groups(*mdl, *st, kLatentWaves) : 0;
+}
 
 int mopoe_latent_lds_bytes(const mopoe_model* mdl, const mopoe_step* st) {
     return latent_lds_bytes(*mdl, *st);

@@ -34,9 +34,9 @@ class Workspace:
                     for m in range(M)]
         self._stats_all = torch.zeros(64 + 128, **f)   # [64:] diagnostic stamps
         self.stats = self._stats_all[:L.NUM_STATS]
-        tiles = (n + L.ROWS - 1) // L.ROWS
-        stride = L.lib.mopoe_partials_stride(spec.c_model)
-        self.partials = torch.zeros(tiles, stride, **f)
+        self._f = f
+        self._stride = L.lib.mopoe_partials_stride(spec.c_model)
+        self.partials = torch.zeros((n + L.ROWS - 1) // L.ROWS, self._stride, **f)
         self.backward = backward
         if backward:
             self.g_xhat = [torch.empty(slots * n, spec.input_dim[m], **f)
@@ -44,6 +44,15 @@ class Workspace:
             self.g_heads = [torch.empty(n, spec.heads_dim(m), **f)
                             for m in range(M)]
             self.g_pre = [torch.empty(n, L.HIDDEN, **f) for m in range(M)]
+
+
+def _ensure_partials(self, groups):
+    """`partials` holds one slab per row group of the step (plan.row_groups())."""
+    if self.partials.shape[0] < groups:
+        self.partials = torch.zeros(groups, self._stride, **self._f)
+
+
+Workspace.ensure_partials = _ensure_partials
 
 
 class MoPoEEngine:
@@ -106,8 +115,10 @@ class MoPoEEngine:
             self._ws[key] = ws
         return ws
 
-    def _buffers(self, ws, x, row_index, stats_host=None):
+    def _buffers(self, ws, x, row_index, stats_host=None, plan=None):
         b = L.Buffers()
+        if plan is not None:
+            ws.ensure_partials(plan.row_groups())
         if stats_host is not None:
             if not stats_host.is_pinned() or stats_host.numel() < L.NUM_STATS:
                 raise ValueError("stats_host must be a pinned float32 tensor of >= %d"
@@ -210,7 +221,7 @@ class MoPoEEngine:
         keep = self._bind_noise(plan, step, eps)
         self._calls += 1
         step.seed = (self.seed + 0x9E3779B97F4A7C15 * self._calls) & (2 ** 64 - 1)
-        buf = self._buffers(ws, x, row_index)
+        buf = self._buffers(ws, x, row_index, plan=plan)
         L.check(L.lib.mopoe_forward(self.spec.c_model, step, buf, L.stream_ptr()),
                 "mopoe_forward")
         self._keep = (x, keep, row_index)
@@ -229,7 +240,7 @@ class MoPoEEngine:
         step = plan.c_step
         keep = self._bind_noise(plan, step, eps)
         step.seed = self.seed
-        buf = self._buffers(ws, x, row_index, stats_host)
+        buf = self._buffers(ws, x, row_index, stats_host, plan=plan)
         adam = C.byref(self.adam) if apply_adam else None
         L.check(L.lib.mopoe_train_step(self.spec.c_model, step, buf, adam,
                                        L.stream_ptr()), "mopoe_train_step")
@@ -284,8 +295,11 @@ class MoPoEEngine:
             logvars = ws.subsets_logvar.index_select(0, idx)
         latents = {
             "modalities": enc_mods, "mus": mus, "logvars": logvars,
-            "weights": torch.tensor(plan.comp_w, dtype=torch.float32,
-                                    device=self.device),
+            # BaseMMVae.py:225: the raw (1/K) weights (the reweighted ones, which
+            # differ in the last bit for some K, only live inside moe_fusion and
+            # calc_group_divergence_moe)
+            "weights": ((1 / float(len(plan.comp_w))) *
+                        torch.ones(len(plan.comp_w))).to(self.device),
             "joint": [ws.joint_mu, ws.joint_logvar], "subsets": subsets}
         res = {"latents": latents, "group_distr": latents["joint"]}
         res["joint_divergence"] = ws.stats[L.STAT_JOINT_DIV]

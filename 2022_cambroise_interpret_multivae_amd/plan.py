@@ -211,6 +211,7 @@ class StepPlan:
         st.present_mask = mask
         st.sample = int(sample)
         st.backward = int(backward)
+        st.rows_per_group = L.rows_per_group()
         st.group_rows = int(group_rows)
         st.num_subsets = len(spec.subset_keys)
 
@@ -315,3 +316,7 @@ class StepPlan:
 
     def lds_bytes(self):
         return L.lib.mopoe_latent_lds_bytes(self.spec.c_model, self.c_step)
+
+    def row_groups(self):
+        """Row groups (= partial slabs) of the fused per-sample kernel for this step."""
+        return L.lib.mopoe_row_groups(self.spec.c_model, self.c_step)

@@ -108,6 +108,10 @@ typedef struct mopoe_step {
     int32_t joint_mode;     /* MOPOE_JOINT_*                                   */
     int32_t expert_subset;  /* subset index for MOPOE_JOINT_EXPERT             */
     int32_t backward;       /* also compute gradients (training step)          */
+    int32_t rows_per_group; /* 0 = the library picks: 16 batch rows per workgroup of the
+                               fused per-sample kernel when its tiles fit the LDS,
+                               else 8, 4, 2 or 1 (wide inputs, five modalities);
+                               1, 2, 4, 8 or 16 pins it                          */
     int32_t group_rows;     /* 0, or rows per logical batch: the n rows are
                                n/group_rows independent batches folded into the
                                batch axis (the repeated forwards of
@@ -187,7 +191,8 @@ typedef struct mopoe_buffers {
     float* g_xhat[MOPOE_MAX_MODS];       /* (R_m, d_m)   d loss / d loc        */
     float* g_heads[MOPOE_MAX_MODS];      /* (n, nh_m)                          */
     float* g_pre[MOPOE_MAX_MODS];        /* (n, 256)     d loss / d pre-relu   */
-    float* partials;                     /* (tiles, mopoe_partials_stride())   */
+    float* partials;                     /* (mopoe_row_groups(model, step),
+                                            mopoe_partials_stride(model))      */
 } mopoe_buffers;
 
 typedef struct mopoe_adam {
@@ -218,9 +223,14 @@ int mopoe_sizeof(int which);
 
 /* leading dimension (floats) of z[m]: round_up(zd_m, 4) */
 int mopoe_ldz(const mopoe_model* model, int mod);
-/* floats per row-tile in `partials` */
+/* floats per row group in `partials` */
 int mopoe_partials_stride(const mopoe_model* model);
-/* bytes of LDS the fused latent kernel needs for this model (<= 160 KiB) */
+/* row groups the fused per-sample kernel cuts the batch into for this step
+ * (= the number of partial slabs the caller provides): ceil(n / rows), rows = 16
+ * unless the LDS carve-up asks for fewer or step->rows_per_group pins it */
+int mopoe_row_groups(const mopoe_model* model, const mopoe_step* step);
+/* bytes of LDS the fused latent kernel needs for this model and step (<= 160 KiB
+ * after the rows-per-group fallback; larger only if even one row does not fit) */
 int mopoe_latent_lds_bytes(const mopoe_model* model, const mopoe_step* step);
 
 /* Replaces BaseMMVae.forward / inference under torch.no_grad()
