@@ -55,6 +55,35 @@ HD int partials_stride(const mopoe_model& m) { return lvo_part_off(m, m.num_mods
 // in place when the modality is decoded once) + the K-split partials of g_z;
 // the per-element KL terms overlay the partials' area until they are reduced.
 // ---------------------------------------------------------------------------
+// Packed descriptors of the element-wise stages (fusion forward / backward).  Those
+// stages used to chase the public descriptor arrays field by field: ~90 scalar loads,
+// most of them waited for on the spot, per wave and stage -- their latency WAS the
+// stage.  Here everything a modality / job / subset contributes sits in one aligned
+// record that one s_load_dwordx8/x16 fetches.
+struct alignas(32) FuseMod {   // LDS offsets in floats
+    int heads, gheads;   // tiles [R][ldh]: style mu | style logvar | content mu | content logvar
+    int ldh, sd;         // leading dimension, style dim
+    int tm, ev;          // [R*D] precision / exp(logvar) of the content posterior
+    int klt_style;       // [R*sd] KL terms of the style posterior
+    int present;
+};
+struct alignas(64) FuseJob {
+    int mod, slot, src, stream;
+    int zj, ldz, epsc, stdc;     // LDS: z tile and its ld, content eps / std [R*D]
+    int epss, stds, gzj, gz_off; // LDS: style eps / std [R*sd], kept g_z, column in the slabs
+    int sd, ldzg, pad0, pad1;    // style dim of the modality, ld of z[m] in HBM
+};
+struct alignas(32) FuseSub {
+    uint32_t desc;       // avail | kind << 1 | mask << 3 | E << 8 | members (3 bits each) << 11
+                         // | is a mixture component << 26
+    int lo, hi;          // rows (inside their logical batch) whose joint latent is this subset
+    uint32_t src_jobs;   // decoder jobs fed by this subset's own distribution (method poe)
+    int f;               // SLICES: rows per member slice
+    float kl_coef;       // d loss / d KL(subset)
+    int pad0, pad1;
+};
+constexpr uint32_t kSubComp = 1u << 26;
+
 struct LatentLds {
     int hs[MOPOE_MAX_MODS];      // R0: hidden tile            [16][kLdH]
     int xs[MOPOE_MAX_MODS];      // R0: input tile             [16][ld_x]
@@ -91,6 +120,12 @@ struct LatentLds {
     int pass_end[MOPOE_MAX_JOBS];      // one past the last job of the pass starting here
     int pres_mod[MOPOE_MAX_MODS];      // k-th present modality
     int npres;
+    int s3_nt;                         // 16-column tiles per decoder unit: 4, or 2 when the
+                                       // 64-column units would leave half the waves idle
+    FuseMod fm[MOPOE_MAX_MODS];
+    FuseJob fj[MOPOE_MAX_JOBS];
+    FuseSub fs[MOPOE_MAX_SUBSETS];
+    uint32_t joint_jobs;               // decoder jobs fed by the joint latent
     int rows;                          // batch rows a group owns (16, 8, 4, 2 or 1)
     int rd;                            // round_up(rows * class_dim, 4): stride of a KL-term slab
     int fits;                          // the carve-up fits the 160 KiB budget
@@ -215,12 +250,19 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
             if ((st.present_mask >> i) & 1) L.pres_mod[L.npres++] = i;
         L.s1_begin[MOPOE_MAX_MODS] = t;
         L.sl_begin[MOPOE_MAX_MODS] = sl;
+        int widest = 0;  // 64-column decoder units of the busiest pass
+        for (int j = 0, u = 0; j < st.num_jobs; ++j) {
+            if (j > 0 && st.job_stream[j] != st.job_stream[j - 1]) u = 0;
+            u += cdiv(m.input_dim[st.job_mod[j]], 64);
+            if (u > widest) widest = u;
+        }
+        L.s3_nt = 2 * widest <= waves ? 2 : 4;
         int u3 = 0, u4 = 0;
         for (int j = 0; j <= MOPOE_MAX_JOBS; ++j) {
             L.s3_begin[j] = u3;
             L.s4_begin[j] = u4;
             if (j < st.num_jobs) {
-                u3 += cdiv(m.input_dim[st.job_mod[j]], 64);
+                u3 += cdiv(m.input_dim[st.job_mod[j]], 16 * L.s3_nt);
                 u4 += cdiv(z_dim(m, st.job_mod[j]), 64) * L.gz_chunks;
             }
         }
@@ -228,6 +270,71 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
             int je = j + 1;
             while (je < st.num_jobs && st.job_stream[je] == st.job_stream[j]) ++je;
             L.pass_end[j] = j < st.num_jobs ? je : j + 1;
+        }
+    }
+    for (int i = 0; i < MOPOE_MAX_MODS; ++i) {
+        FuseMod& f = L.fm[i];
+        f.present = i < m.num_mods && ((st.present_mask >> i) & 1);
+        f.heads = L.heads[i];
+        f.gheads = L.gheads[i];
+        f.ldh = i < m.num_mods ? ld_heads_lds(m, i) : 0;
+        f.sd = i < m.num_mods ? m.style_dim[i] : 0;
+        f.tm = L.tm[i];
+        f.ev = L.ev[i];
+        f.klt_style = L.klt_style[i];
+    }
+    L.joint_jobs = 0;
+    for (int j = 0; j < MOPOE_MAX_JOBS; ++j) {
+        FuseJob& f = L.fj[j];
+        const bool on = j < st.num_jobs;
+        const int i = on ? st.job_mod[j] : 0;
+        f.mod = i;
+        f.slot = on ? st.job_slot[j] : 0;
+        f.src = on ? st.job_src[j] : 0;
+        f.stream = on ? st.job_stream[j] : 0;
+        f.zj = L.zj[j];
+        f.ldz = ld_z_lds(m, i);
+        f.epsc = L.epsc[j];
+        f.stdc = L.stdc[j];
+        f.epss = L.epss[j];
+        f.stds = L.stds[j];
+        f.gzj = L.gzj[j];
+        f.gz_off = L.gz_off[j];
+        f.sd = m.style_dim[i];
+        f.ldzg = ldz_glb(m, i);
+        f.pad0 = f.pad1 = 0;
+        if (on && st.job_src[j] < 0) L.joint_jobs |= 1u << j;
+    }
+    for (int k = 0; k < MOPOE_MAX_SUBSETS; ++k) {
+        FuseSub& f = L.fs[k];
+        const bool on = k < st.num_subsets;
+        uint32_t desc = 0, nmem = 0;
+        if (on) {
+            for (int b = 0; b < MOPOE_MAX_MODS; ++b) nmem += (st.sub_mask[k] >> b) & 1;
+            desc = (uint32_t)(st.sub_avail[k] != 0) | ((uint32_t)st.sub_kind[k] << 1) |
+                   ((uint32_t)st.sub_mask[k] << 3) | (nmem << 8);
+            for (int b = 0; b < MOPOE_MAX_MODS; ++b)
+                desc |= ((uint32_t)st.sub_members[k][b] & 7u) << (11 + 3 * b);
+        }
+        f.desc = desc;
+        f.lo = f.hi = 0;
+        f.src_jobs = 0;
+        f.f = on ? st.sub_f[k] : 0;
+        f.kl_coef = on ? st.sub_kl_coef[k] : 0.f;
+        f.pad0 = f.pad1 = 0;
+        for (int j = 0; j < st.num_jobs; ++j)
+            if (on && st.job_src[j] == k) f.src_jobs |= 1u << j;
+    }
+    if (st.joint_mode == MOPOE_JOINT_EXPERT) {
+        L.fs[st.expert_subset].hi = 0x7fffffff;
+    } else {
+        for (int k = 0; k < st.num_comp; ++k) {
+            FuseSub& f = L.fs[st.comp_sub[k]];
+            f.desc |= kSubComp;
+            if (st.joint_mode == MOPOE_JOINT_MIXTURE) {  // utils/utils.py:63-85
+                f.lo = k * st.comp_f;
+                f.hi = k == st.num_comp - 1 ? 0x7fffffff : (k + 1) * st.comp_f;
+            }
         }
     }
     return fits;

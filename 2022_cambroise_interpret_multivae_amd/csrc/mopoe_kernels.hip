@@ -95,7 +95,7 @@ struct KArgs {
     mopoe_buffers buf;
     LatentLds lds;  // carve-up of k_latent's LDS, computed on the host
 };
-static_assert(sizeof(KArgs) <= 3500, "kernel argument block too large");
+static_assert(sizeof(KArgs) <= 6144, "kernel argument block too large");  // (12 KB launches fine: tools/kernarg_probe.hip)
 
 DEV int src_row(const mopoe_buffers& buf, int m, int gn) {
     return buf.row_index[m] ? buf.row_index[m][gn] : gn;
