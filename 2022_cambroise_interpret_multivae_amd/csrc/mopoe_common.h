@@ -83,6 +83,27 @@ struct alignas(32) FuseSub {
     int pad0, pad1;
 };
 constexpr uint32_t kSubComp = 1u << 26;
+struct alignas(64) DecJob {   // decoder stages (x_hat and d loss / d z), per decoder job
+    int mod, slot, dm, zd;
+    int ldz, ldx, zj, xs;            // LDS: ld of the z / x tiles, z tile, x tile
+    int gx, gz_off, off_wd, off_bd;  // LDS: g_xhat tile, column in the g_z slabs; parameters
+    int off_lvo, lvo_part, nblk_z, nblk_d;  // lvo_part: this job's slot in a group's partials
+    float nll_coef;
+    int pad0, pad1, pad2;
+    float* loc;                      // buffers.loc[mod], buffers.g_xhat[mod]
+    float* g_xhat;
+    int pad3[8];
+};
+struct alignas(64) EncMod {   // encoder-side stages (heads GEMM, d loss / d h), per modality
+    int nh, ldh, off_wh, off_bh;
+    int hs, heads, gheads, present;  // LDS: hidden tile, heads tile, its gradient
+    int d, ldx, xs, nblk_h;
+    const float* hidden;             // buffers.hidden / heads / g_pre / g_heads [mod]
+    float* heads_out;
+    float* g_pre;
+    float* g_heads;
+    int pad[12];
+};
 
 struct LatentLds {
     int hs[MOPOE_MAX_MODS];      // R0: hidden tile            [16][kLdH]
@@ -126,6 +147,8 @@ struct LatentLds {
     FuseJob fj[MOPOE_MAX_JOBS];
     FuseSub fs[MOPOE_MAX_SUBSETS];
     uint32_t joint_jobs;               // decoder jobs fed by the joint latent
+    DecJob dj[MOPOE_MAX_JOBS];
+    EncMod em[MOPOE_MAX_MODS];
     int rows;                          // batch rows a group owns (16, 8, 4, 2 or 1)
     int rd;                            // round_up(rows * class_dim, 4): stride of a KL-term slab
     int fits;                          // the carve-up fits the 160 KiB budget
@@ -325,6 +348,50 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
         for (int j = 0; j < st.num_jobs; ++j)
             if (on && st.job_src[j] == k) f.src_jobs |= 1u << j;
     }
+    for (int j = 0; j < MOPOE_MAX_JOBS; ++j) {
+        DecJob& f = L.dj[j];
+        const bool on = j < st.num_jobs;
+        const int i = on ? st.job_mod[j] : 0;
+        f.mod = i;
+        f.slot = on ? st.job_slot[j] : 0;
+        f.dm = m.input_dim[i];
+        f.zd = z_dim(m, i);
+        f.ldz = ld_z_lds(m, i);
+        f.ldx = ld_x_lds(m, i);
+        f.zj = L.zj[j];
+        f.xs = L.xs[i];
+        f.gx = L.gx[i];
+        f.gz_off = L.gz_off[j];
+        f.off_wd = m.off_wd[i];
+        f.off_bd = m.off_bd[i];
+        f.off_lvo = m.off_lvo[i];
+        f.lvo_part = L.lvo_off[i] + f.slot * lvo_slot_stride(m, i);
+        f.nblk_z = round_up(f.zd, 16) / 16;
+        f.nblk_d = round_up(f.dm, 16) / 16;
+        f.nll_coef = on ? st.job_nll_coef[j] : 0.f;
+        f.pad0 = f.pad1 = f.pad2 = 0;
+        f.loc = f.g_xhat = nullptr;   // latent_bind()
+        for (int k = 0; k < 8; ++k) f.pad3[k] = 0;
+    }
+    for (int i = 0; i < MOPOE_MAX_MODS; ++i) {
+        EncMod& f = L.em[i];
+        const bool on = i < m.num_mods;
+        f.nh = on ? heads_dim(m, i) : 0;
+        f.ldh = on ? ld_heads_lds(m, i) : 0;
+        f.off_wh = on ? m.off_wh[i] : 0;
+        f.off_bh = on ? m.off_bh[i] : 0;
+        f.hs = L.hs[i];
+        f.heads = L.heads[i];
+        f.gheads = L.gheads[i];
+        f.present = on && ((st.present_mask >> i) & 1);
+        f.d = on ? m.input_dim[i] : 0;
+        f.ldx = on ? ld_x_lds(m, i) : 0;
+        f.xs = L.xs[i];
+        f.nblk_h = round_up(f.nh, 16) / 16;
+        f.hidden = nullptr;
+        f.heads_out = f.g_pre = f.g_heads = nullptr;
+        for (int k = 0; k < 12; ++k) f.pad[k] = 0;
+    }
     if (st.joint_mode == MOPOE_JOINT_EXPERT) {
         L.fs[st.expert_subset].hi = 0x7fffffff;
     } else {
@@ -355,6 +422,19 @@ HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
     for (int R = kRows; R >= 1; R /= 2) {
         L.fits = latent_lds_layout_rows(m, st, waves, R, L);
         if (L.fits) return;
+    }
+}
+// the caller's buffer pointers into the per-job / per-modality records
+HD void latent_bind(LatentLds& L, const mopoe_buffers& b) {
+    for (int j = 0; j < MOPOE_MAX_JOBS; ++j) {
+        L.dj[j].loc = b.loc[L.dj[j].mod];
+        L.dj[j].g_xhat = b.g_xhat[L.dj[j].mod];
+    }
+    for (int i = 0; i < MOPOE_MAX_MODS; ++i) {
+        L.em[i].hidden = b.hidden[i];
+        L.em[i].heads_out = b.heads[i];
+        L.em[i].g_pre = b.g_pre[i];
+        L.em[i].g_heads = b.g_heads[i];
     }
 }
 HD int latent_groups(const mopoe_model& m, const mopoe_step& st, int waves) {

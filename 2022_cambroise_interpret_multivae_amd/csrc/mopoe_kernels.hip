@@ -95,7 +95,7 @@ struct KArgs {
     mopoe_buffers buf;
     LatentLds lds;  // carve-up of k_latent's LDS, computed on the host
 };
-static_assert(sizeof(KArgs) <= 6144, "kernel argument block too large");  // (12 KB launches fine: tools/kernarg_probe.hip)
+static_assert(sizeof(KArgs) <= 8192, "kernel argument block too large");  // (12 KB launches fine: tools/kernarg_probe.hip)
 
 DEV int src_row(const mopoe_buffers& buf, int m, int gn) {
     return buf.row_index[m] ? buf.row_index[m][gn] : gn;
@@ -1160,6 +1160,7 @@ int mopoe_forward(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buff
     ka.buf = *buf;
     ka.st.backward = 0;
     latent_lds_layout(ka.mdl, ka.st, kLatentWaves, ka.lds);
+    latent_bind(ka.lds, ka.buf);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = launch_forward_part(ka, nullptr, s)) return rc;
     {
@@ -1181,6 +1182,7 @@ int mopoe_train_step(const mopoe_model* mdl, const mopoe_step* st, const mopoe_b
     ka.st.backward = 1;
     ka.st.sample = 1;
     latent_lds_layout(ka.mdl, ka.st, kLatentWaves, ka.lds);
+    latent_bind(ka.lds, ka.buf);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = launch_forward_part(ka, adam, s)) return rc;
     WArgs w;
