@@ -455,6 +455,23 @@ DEV f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// A packed descriptor record out of the argument block, fetched whole: 8-dword vector
+// loads, which become s_load_dwordx8 (left to itself the compiler loads the fields one
+// dword at a time, next to their uses, and waits for each).
+template <class T>
+DEV T load_rec(const T& src) {
+    static_assert(sizeof(T) % 32 == 0 && alignof(T) >= 32, "records are 32-byte multiples");
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    union U {
+        T t;
+        v8i v[sizeof(T) / 32];
+        DEV U() {}
+    } u;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 32; ++i) u.v[i] = reinterpret_cast<const v8i*>(&src)[i];
+    return u.t;
+}
+
 // index of the segment of a prefix table (begin[0..NSEG]) that holds u
 template <int NSEG>
 DEV int find_seg(const int (&begin)[NSEG + 1], int u) {
