@@ -485,7 +485,7 @@ struct WArgs {
 //   B fragments  X[r][j0 + 2c + tj]   -> output columns j = j0 + 2c + tj
 // (column-interleaved 16x16 tiles, as in k_latent).  The bias gradient is the
 // column of an implicit all-ones feature at j == xcols.
-template <bool GATHER>
+template <bool GATHER, int STEPS>  // STEPS MFMA steps (4 batch rows each) per round: 16 or 8
 DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int ldg_, int ldx,
                     int gcols, int xcols, int i0, int j0, int rbeg, int rend, int lane,
                     f32x4 (&acc)[2][2]) {
@@ -496,16 +496,16 @@ DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int
     const uint32_t am0 = ci < gcols ? 0xFFFFFFFFu : 0u, am1 = ci + 1 < gcols ? 0xFFFFFFFFu : 0u;
     const uint32_t bm0 = cj < xcols ? 0xFFFFFFFFu : 0u, bm1 = cj + 1 < xcols ? 0xFFFFFFFFu : 0u;
     const float one0 = cj == xcols ? 1.f : 0.f, one1 = cj + 1 == xcols ? 1.f : 0.f;
-    for (int rb = rbeg; rb < rend; rb += 64) {
-        int xrow[16];
+    for (int rb = rbeg; rb < rend; rb += 4 * STEPS) {
+        int xrow[STEPS];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < STEPS; ++s) {
             const int r = rb + 4 * s + q;
             xrow[s] = GATHER ? xrows[min(r, rend - 1)] : r;
         }
-        f32x2 av[16], bv[16];
+        f32x2 av[STEPS], bv[STEPS];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < STEPS; ++s) {
             const int r = rb + 4 * s + q;
             const bool rv = r < rend;
             av[s] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
@@ -514,7 +514,7 @@ DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int
                         xr, guard((uint32_t)(xrow[s] * ldx + cj) * 4u, rv & (cj < xcols)), 0, 0));
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < STEPS; ++s) {
             const bool rv = rb + 4 * s + q < rend;
             // columns past the end of a row hold the next row's values: mask them
             const float a0 = av[s][0], a1 = av[s][1], b0 = bv[s][0], b1 = bv[s][1];
@@ -534,11 +534,26 @@ DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int
 
 constexpr int kWgLd = 36;  // leading dim of a 32x32 partial block in LDS
 
-__global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
-    __shared__ __attribute__((aligned(16))) float blk[4][32 * kWgLd];
+// kWgWaves waves split the batch rows of a block: 8 for large batches (twice as fast at
+// N >= 1024), 4 for small ones (at N = 256 the longer reduction and the larger
+// workgroups cost more than the shorter MFMA chains save).
+template <int kWgWaves>
+__global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
+                                                         const WArgs w_by_value) {
+    __shared__ __attribute__((aligned(16))) float blk[kWgWaves][32 * kWgLd];
+    (void)a_by_value;  // both argument blocks are read in place (see k_latent)
+    (void)w_by_value;
+    static_assert(sizeof(KArgs) % alignof(WArgs) == 0, "WArgs follows KArgs without padding");
+    const char* kargs = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    const KArgs& a = *(const KArgs*)kargs;
+    const WArgs& w = *(const WArgs*)(kargs + sizeof(KArgs));
     const mopoe_buffers& buf = a.buf;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform (T20)
+    // the block's tables (tile -> job record -> pointers) into the scalar cache
+    uint32_t karg_sink = 0;
+    for (int line = wave; line < (int)(sizeof(WArgs) / 64); line += kWgWaves)
+        karg_sink |= ((const uint32_t*)(kargs + sizeof(KArgs)))[line * 16];
     const int b = blockIdx.x;
     const bool fuse = w.fuse_adam != 0;
     const bool stamp_blk = b == 20 && tid == 0;  // a W1 block of the large modality
@@ -557,9 +572,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
         const int R = job.R, gcols = job.gcols, xcols = job.xcols;
 
         // epilogue ownership: thread -> output row i0 + tid/8, columns j0 + 4*(tid%8) ..+3
-        const int ei = i0 + (tid >> 3), ej = j0 + 4 * (tid & 7);
-        const int nvalid = ei < gcols ? min(xcols - ej, 4) : 0;   // weight columns
-        const bool has_b = (ei < gcols) & (xcols >= ej) & (xcols < ej + 4) & (job.off_b >= 0);
+        const bool epi = tid < 256;  // the first four waves own the 32x32 outputs
+        const int ei = i0 + ((tid & 255) >> 3), ej = j0 + 4 * (tid & 7);
+        const int nvalid = (epi & (ei < gcols)) ? min(xcols - ej, 4) : 0;   // weight columns
+        const bool has_b = epi & (ei < gcols) & (xcols >= ej) & (xcols < ej + 4) & (job.off_b >= 0);
         const int widx = job.off_w + ei * xcols + ej;
         const int bidx = job.off_b + ei;
         const size_t pbytes = (size_t)a.mdl.num_floats * sizeof(float);
@@ -584,18 +600,30 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
         }
 
         GSTAMP(buf.stats, 64 + 41, stamp_blk);
-        const int rq = round_up(cdiv(R, 4), 4);
+        const int rq = round_up(cdiv(R, kWgWaves), 4);
         const int rbeg = wave * rq, rend = min(rbeg + rq, R);
         const rsrc_t gr = make_rsrc(job.G, (size_t)R * job.ldg * sizeof(float));
         const rsrc_t xr = make_rsrc_max(job.X);
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         f32x4 acc[2][2] = {{z4, z4}, {z4, z4}};
-        if (job.xrows)
-            wgrad_rows<true>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0, rbeg, rend,
-                             lane, acc);
-        else
-            wgrad_rows<false>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0, rbeg, rend,
-                              lane, acc);
+        // rounds of 64 batch rows (32 loads in flight), or of 32 when a wave's share is
+        // no more than that (the padded steps of a long round would still issue MFMAs)
+        const bool half = rq <= 32;
+        if (job.xrows) {
+            if (half)
+                wgrad_rows<true, 8>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                    rbeg, rend, lane, acc);
+            else
+                wgrad_rows<true, 16>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                     rbeg, rend, lane, acc);
+        } else {
+            if (half)
+                wgrad_rows<false, 8>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                     rbeg, rend, lane, acc);
+            else
+                wgrad_rows<false, 16>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                      rbeg, rend, lane, acc);
+        }
         GSTAMP(buf.stats, 64 + 42, stamp_blk);
         // this wave's partial block -> LDS as [i][j]
         {
@@ -610,11 +638,13 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
         }
         __syncthreads();
         // fixed-order sum of the four partials, 4 consecutive columns per thread
+        asm volatile("" ::"s"(karg_sink));  // (keeps the prefetch loads alive)
+        if (!epi) return;
         const int li = tid >> 3, lj = 4 * (tid & 7);
         f32x4 g = *reinterpret_cast<const f32x4*>(&blk[0][li * kWgLd + lj]);
-        g += *reinterpret_cast<const f32x4*>(&blk[1][li * kWgLd + lj]);
-        g += *reinterpret_cast<const f32x4*>(&blk[2][li * kWgLd + lj]);
-        g += *reinterpret_cast<const f32x4*>(&blk[3][li * kWgLd + lj]);
+#pragma unroll
+        for (int k = 1; k < kWgWaves; ++k)  // fixed order
+            g += *reinterpret_cast<const f32x4*>(&blk[k][li * kWgLd + lj]);
         GSTAMP(buf.stats, 64 + 43, stamp_blk);
         AdamCoef ac;
         if (fuse) ac = adam_coef_resolve(acr, w.adam);
@@ -663,10 +693,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
     if (fuse) ac = adam_coef_load(buf.counters, w.adam);
     const int lb = b - w.total_tiles;
     if (lb < w.lvo_blocks) {
+        GSTAMP(buf.stats, 64 + 62, lb == w.lvo_blocks - 1 && tid == 0);
         const int tiles = cdiv(a.st.n, a.lds.rows);
         const int stride = a.lds.part_stride;
         // d loss / d decoders.<m>.logvar: sum of the row groups' partials.  A block
-        // owns 64 columns; its four waves take a quarter of the groups each (four
+        // owns 64 columns; its waves take an equal share of the groups each (four
         // loads in flight per thread) and are added in fixed order through LDS.
         int m = 0;
         while (lb >= w.lvo_block_begin[m + 1]) ++m;
@@ -676,7 +707,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
         if (on) {
             int slots = 0;
             for (int j = 0; j < a.st.num_jobs; ++j) slots += a.st.job_mod[j] == m;
-            const int per = cdiv(tiles, 4);
+            const int per = cdiv(tiles, kWgWaves);
             const int t0 = wave * per, t1 = min(t0 + per, tiles);
             for (int sl = 0; sl < slots; ++sl) {
                 const float* p = buf.partials + a.lds.lvo_off[m] +
@@ -696,7 +727,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
         blk[0][wave * 64 + lane] = g;
         __syncthreads();
         if (on && wave == 0) {
-            g = ((blk[0][lane] + blk[0][64 + lane]) + blk[0][128 + lane]) + blk[0][192 + lane];
+            g = 0.f;
+#pragma unroll
+            for (int k = 0; k < kWgWaves; ++k) g += blk[0][k * 64 + lane];  // fixed order
             const int idx = a.mdl.off_lvo[m] + col;
             if (a.mdl.learn_output_scale) {
                 buf.grads[idx] = g;
@@ -708,10 +741,13 @@ __global__ __launch_bounds__(256) void k_wgrad(const KArgs a, const WArgs w) {
                 buf.grads[idx] = 0.f;
             }
         }
+        GSTAMP(buf.stats, 64 + 63, lb == w.lvo_blocks - 1 && tid == 0);
         return;
     }
     // last block: scalars of the step (run_epochs.py:89-128) + step counter
-    finalize_stats<4>(a, tid);
+    GSTAMP(buf.stats, 64 + 60, tid == 0);
+    finalize_stats<kWgWaves>(a, tid);
+    GSTAMP(buf.stats, 64 + 61, tid == 0);
     if (tid == 0 && a.st.backward) buf.counters[1] += 1;
 }
 
@@ -1189,7 +1225,11 @@ int mopoe_train_step(const mopoe_model* mdl, const mopoe_step* st, const mopoe_b
     build_wargs(ka, adam, w);
     {
         ProfScope ps(MOPOE_KERNEL_WGRAD, s);
-        hipLaunchKernelGGL(k_wgrad, dim3(w.total_tiles + w.lvo_blocks + 1), dim3(256), 0, s, ka,
+        if (ka.st.n > 512)
+            hipLaunchKernelGGL(k_wgrad<8>, dim3(w.total_tiles + w.lvo_blocks + 1), dim3(512), 0, s,
+                               ka, w);
+        else
+            hipLaunchKernelGGL(k_wgrad<4>, dim3(w.total_tiles + w.lvo_blocks + 1), dim3(256), 0, s, ka,
                            w);
     }
     return check_launch("k_wgrad");

@@ -15,7 +15,7 @@ for i in range(300): eng.train_step(pool[i % 8])
 torch.cuda.synchronize()
 names = ["k_linear entry", "k_linear row index staged", "k_linear x tile staged", "k_linear MFMA done", "k_linear exit", "k_latent entry", "k_latent stamp0", "k_latent last stage end", "k_latent exit",
          "k_wgrad entry", "k_wgrad decoded, Adam operands requested", "k_wgrad GEMM done", "k_wgrad block reduced", "k_wgrad exit",
-         "next k_linear entry"]
+         "k_wgrad finalize block entry", "k_wgrad finalize block exit", "k_wgrad last logvar block entry", "k_wgrad last logvar block exit"]
 acc = None
 prev = None
 rows = []
@@ -25,7 +25,8 @@ for it in range(60):
     s = ws._stats_all.cpu().view(torch.int32)
     lat = s[64:64 + 32].view(16, 2)
     cur = [int(c[11]), int(c[13]), int(c[14]), int(c[15]), int(c[12]), int(s[64 + 45]), int(lat[0, 0]), int(lat[10, 0]), int(s[64 + 46]),
-           int(s[64 + 40]), int(s[64 + 41]), int(s[64 + 42]), int(s[64 + 43]), int(s[64 + 44])]
+           int(s[64 + 40]), int(s[64 + 41]), int(s[64 + 42]), int(s[64 + 43]), int(s[64 + 44]),
+           int(s[64 + 60]), int(s[64 + 61]), int(s[64 + 62]), int(s[64 + 63])]
     rows.append(cur)
 import numpy as np
 r = np.array(rows, dtype=np.int64) & 0xFFFFFFFF
