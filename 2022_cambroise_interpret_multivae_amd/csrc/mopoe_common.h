@@ -533,6 +533,13 @@ DEV float ldg(rsrc_t r, uint32_t byte_off) {
 DEV f32x4 ldg4(rsrc_t r, uint32_t byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
+// 16-byte WRITE-THROUGH store (sc1): the line does not stay dirty in the XCD's L2, so
+// it is on its way to memory while the kernel still runs instead of being flushed when
+// the kernel ends (the consumer is the next kernel, on any XCD, through memory anyway).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+DEV void stg4_wt(rsrc_t r, uint32_t byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 16);
+}
 
 // B fragment of Y = A * W^T: W is (ncols, K) row-major with row stride ldw;
 // r covers ncols * ldw floats, so col >= ncols is out of range by itself.

@@ -661,11 +661,12 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
                 }
             }
             if (nvalid >= 4) {
-                *reinterpret_cast<f32x4*>(buf.grads + widx) = g;
+                const rsrc_t rg = make_rsrc(buf.grads, pbytes);
+                stg4_wt(rg, (uint32_t)widx * 4u, g);
                 if (fuse) {
-                    *reinterpret_cast<f32x4*>(buf.params + widx) = np;
-                    *reinterpret_cast<f32x4*>(buf.exp_avg + widx) = nm;
-                    *reinterpret_cast<f32x4*>(buf.exp_avg_sq + widx) = nv;
+                    stg4_wt(rp, (uint32_t)widx * 4u, np);
+                    stg4_wt(rm, (uint32_t)widx * 4u, nm);
+                    stg4_wt(rv, (uint32_t)widx * 4u, nv);
                 }
             } else {
                 for (int e = 0; e < nvalid; ++e) {
