@@ -559,141 +559,6 @@ DEV f32x4 glb_b4_nt(rsrc_t r, int ldw, int K, int j0, int kb, int lane) {
     return v;
 }
 
-// B fragment of Y = A * B: B is (K, ncols) row-major with row stride ldb;
-// r covers K * ldb floats, so k >= K is out of range by itself.
-DEV f32x4 glb_b4_nn(rsrc_t r, int ldb, int ncols, int j0, int kb, int lane) {
-    const int col = j0 + (lane & 15);
-    const int k = kb + 4 * (lane >> 4);
-    const uint32_t base = (uint32_t)(k * ldb + col) * 4u;
-    f32x4 v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        v[i] = ldg(r, guard(base + (uint32_t)(i * ldb) * 4u, col < ncols));
-    return v;
-}
-
-// ---------------------------------------------------------------------------
-// Tile GEMM machinery.  One "unit" = one 16x16 output tile (or one K-slice of
-// it): A (16 x K, zero padded to a multiple of 16) sits in LDS, B is streamed
-// from global/L2 straight into registers -- each B element is used by exactly
-// one wave of the workgroup, so an LDS round trip would be pure overhead.
-// The step is latency-bound, so what matters is how many loads are in flight:
-// all B fragments of a batch (CH blocks of 16 k) are requested before the
-// first MFMA of the batch, and the NEXT unit's first batch (plus whatever its
-// epilogue will need from global memory) is requested before the current
-// unit's MFMAs start.
-// ---------------------------------------------------------------------------
-struct GemmUnit {
-    const float* As;  // LDS A tile [16][lda]
-    const float* B;   // global B operand
-    int lda, ldb, ncols, K, j0, kbeg, kend;
-    int vec;          // NT only: K % 4 == 0 (4-wide reads stay inside a row)
-    int tag, tag2;    // stage-specific
-};
-
-template <bool NT, int CH>
-DEV void load_batch(const GemmUnit& u, int kb, f32x4 (&b)[CH], int lane) {
-    if (NT) {
-        const rsrc_t r = make_rsrc(u.B, (size_t)u.ncols * u.ldb * sizeof(float));
-        if (u.vec) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                b[c] = glb_b4_nt<true>(r, u.ldb, u.K, u.j0, kb + 16 * c, lane);
-        } else {
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                b[c] = glb_b4_nt<false>(r, u.ldb, u.K, u.j0, kb + 16 * c, lane);
-        }
-    } else {
-        const rsrc_t r = make_rsrc(u.B, (size_t)u.K * u.ldb * sizeof(float));
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-            b[c] = glb_b4_nn(r, u.ldb, u.ncols, u.j0, kb + 16 * c, lane);
-    }
-}
-
-template <int CH>
-DEV void mma_batch(const GemmUnit& u, int kb, const f32x4 (&b)[CH], f32x4& acc,
-                   f32x4& acc2, int lane) {
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int k = kb + 16 * c;
-        if (k < u.kend) {  // wave-uniform
-            const f32x4 a = lds_a4(u.As, u.lda, k, lane);
-            // two accumulators: the 16x16x4 f32 MFMA has a 40-cycle dependent
-            // latency against a 32-cycle issue interval
-            acc = mfma_16x16x4(a[0], b[c][0], acc);
-            acc2 = mfma_16x16x4(a[1], b[c][1], acc2);
-            acc = mfma_16x16x4(a[2], b[c][2], acc);
-            acc2 = mfma_16x16x4(a[3], b[c][3], acc2);
-        }
-    }
-}
-
-// Runs the units first, first+stride, ... of one wave.  get_unit(idx, unit)
-// fills the descriptor and returns false past the end; prefetch(unit) issues
-// the global loads the unit's epilogue will need and returns them; epilogue
-// (unit, acc, extra) consumes the finished tile.
-#ifdef MOPOE_STAMPS
-#define USTAMP(p, i) \
-    do { if (p) (p)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define USTAMP(p, i) do { } while (0)
-#endif
-
-template <bool NT, int CH, class Get, class Pre, class Epi>
-DEV void run_units(int first, int stride, int lane, Get get_unit, Pre prefetch,
-                   Epi epilogue, unsigned long long* sp = nullptr) {
-    GemmUnit cur, nxt;
-    int idx = first;
-    bool has = get_unit(idx, cur);
-    f32x4 b[CH];
-    using Extra = decltype(prefetch(cur));
-    Extra extra{};
-    USTAMP(sp, 0);
-    if (has) {
-        load_batch<NT, CH>(cur, cur.kbeg, b, lane);
-        extra = prefetch(cur);
-    }
-    USTAMP(sp, 1);
-    int ucount = 0;
-    while (has) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-        Extra extran{};
-        bool hasn = false;
-        for (int kb = cur.kbeg;; kb += 16 * CH) {
-            const bool last = kb + 16 * CH >= cur.kend;
-            f32x4 bn[CH];
-            if (!last) {  // K longer than one batch: next batch of this unit
-                load_batch<NT, CH>(cur, kb + 16 * CH, bn, lane);
-            } else {      // next unit's first batch + what its epilogue needs
-                idx += stride;
-                hasn = get_unit(idx, nxt);
-                if (hasn) {
-                    load_batch<NT, CH>(nxt, nxt.kbeg, bn, lane);
-                    extran = prefetch(nxt);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) bn[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            if (ucount == 0) USTAMP(sp, 2);
-            mma_batch<CH>(cur, kb, b, acc, acc2, lane);
-            if (ucount == 0) USTAMP(sp, 3);
-#pragma unroll
-            for (int c = 0; c < CH; ++c) b[c] = bn[c];
-            if (last) break;
-        }
-        epilogue(cur, acc + acc2, extra);
-        if (ucount == 0) USTAMP(sp, 4);
-        ++ucount;
-        cur = nxt;
-        has = hasn;
-        extra = extran;
-    }
-    USTAMP(sp, 5);
-}
-
 // Philox4x32-10 -> one standard normal (Box-Muller).  Counter = (element,
 // stream, step, tag), key = seed.
 DEV float philox_normal(uint64_t seed, uint32_t step, uint32_t stream, uint32_t idx) {

@@ -2,9 +2,9 @@
 // step and the C ABI declared in include/mopoe_hip.h.
 //
 // One training step = three launches on the caller's stream:
-//   k_enc_hidden   h_m = relu(x_m W1_m^T + b1_m)            (MFMA, grid over
+//   k_linear       h_m = relu(x_m W1_m^T + b1_m)            (MFMA, grid over
 //                  row tiles x hidden column groups x modalities)
-//   k_latent       per 16-row tile, everything that is per-sample: encoder
+//   k_latent       per 16-row group, everything that is per-sample: encoder
 //                  heads (MFMA), powerset-of-experts fusion + KL + mixture
 //                  selection + reparameterisation (VALU, wave reductions),
 //                  decoder + Gaussian NLL (MFMA + epilogue) and the whole
@@ -85,10 +85,6 @@ constexpr float kPoeEps = 1e-8f;
     do {                     \
     } while (0)
 #endif
-#define STOP_AFTER(buf, i) \
-    do {                   \
-    } while (0)
-
 struct KArgs {
     mopoe_model mdl;
     mopoe_step st;
