@@ -351,6 +351,120 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
     GSTAMP(a.counters, 12, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
 }
 
+// ---------------------------------------------------------------------------
+// k_linear_big: the same product for LARGE batches (>= kLinBigRows rows: folded DAA
+// inference, big training batches).  A 16-row tile re-reads its 114 KB of W per
+// workgroup (4 flop per byte of L2 traffic: L2-bound at ~35 TFLOP/s); here a
+// workgroup owns 64 rows x 64 columns, stages x AND W chunks of 64 k through LDS
+// (double buffered: the next chunk is in registers while the current one feeds the
+// MFMAs), and each of its four waves accumulates a 16 x 64 strip -> 16 flop per byte.
+// grid = (column groups of 64, row tiles of 64, groups), block = 256.
+// ---------------------------------------------------------------------------
+constexpr int kBigRows = 64, kBigCols = 64, kBigK = 64, kBigLd = kBigK + 4;
+constexpr int kLinBigRows = 2048;  // batches from here on use it
+
+__global__ __launch_bounds__(256) void k_linear_big(const LinArgs a_by_value) {
+    (void)a_by_value;  // read in place (see k_latent)
+    const LinArgs& a = *(const LinArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    __shared__ __attribute__((aligned(16))) float As[2][kBigRows * kBigLd];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kBigCols * kBigLd];
+    __shared__ int rowsel[kBigRows];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, q = lane >> 4;
+    const int N = a.n;
+    if (a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+        const int t = a.counters[0] + 1;  // training step number (Adam, Philox)
+        a.counters[0] = t;
+        if (a.publish) {
+            *reinterpret_cast<AdamCoef*>(a.counters + kCoefBase) = adam_coef(a.adam, t);
+            a.counters[kCoefTag] = t;
+        }
+    }
+    const LinGroup& g = a.g[blockIdx.z];
+    const int j0 = blockIdx.x * kBigCols, n0 = blockIdx.y * kBigRows;
+    if (j0 >= g.ncols) return;
+    const int K = g.K;
+    if (tid < kBigRows) {
+        const int gn = min(n0 + tid, N - 1);
+        rowsel[tid] = g.rows ? g.rows[gn] : gn;
+    }
+    __syncthreads();
+    const rsrc_t xr = make_rsrc_max(g.X);
+    const rsrc_t wr = make_rsrc(g.W, (size_t)g.ncols * K * sizeof(float));
+    const bool vec = K % 4 == 0;
+    // staging: thread -> 4 float4 of the x chunk and 4 of the W chunk (rows r0 + 16 i)
+    const int r0 = tid >> 4, k4 = (tid & 15) * 4;
+    f32x4 xa[4], wb[4];
+    auto fetch = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 16 * i, k = kc + k4;
+            const uint32_t xo = (uint32_t)(rowsel[r] * g.ldx + k) * 4u;
+            const uint32_t wo = (uint32_t)((j0 + r) * K + k) * 4u;   // row >= ncols: out of range
+            const bool rv = n0 + r < N;
+            if (vec) {
+                xa[i] = ldg4(xr, guard(xo, rv & (k < K)));
+                wb[i] = ldg4(wr, guard(wo, k < K));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xa[i][e] = ldg(xr, guard(xo + 4u * e, rv & (k + e < K)));
+                    wb[i][e] = ldg(wr, guard(wo + 4u * e, k + e < K));
+                }
+            }
+        }
+    };
+    auto park = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 16 * i;
+            *reinterpret_cast<f32x4*>(&As[buf][r * kBigLd + k4]) = xa[i];
+            *reinterpret_cast<f32x4*>(&Bs[buf][r * kBigLd + k4]) = wb[i];
+        }
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4] = {zero4, zero4, zero4, zero4};
+    fetch(0);
+    park(0);
+    __syncthreads();
+    const int nchunks = cdiv(K, kBigK);
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunks) fetch((c + 1) * kBigK);   // in flight under the MFMAs
+        const float* Aw = &As[cur][(wave * 16) * kBigLd];
+#pragma unroll
+        for (int kb = 0; kb < kBigK; kb += 16) {
+            const f32x4 av = lds_a4(Aw, kBigLd, kb, lane);
+            f32x4 bv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bv[t] = lds_a4(&Bs[cur][(16 * t) * kBigLd], kBigLd, kb, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = mfma_16x16x4(av[i], bv[t][i], acc[t]);
+        }
+        if (c + 1 < nchunks) {
+            park(cur ^ 1);   // the other buffer was last read before the previous barrier
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = j0 + 16 * t + c16;
+        if (col >= g.ncols) continue;
+        const float bias = g.b ? g.b[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gn = n0 + wave * 16 + 4 * q + r;
+            if (gn < N) {
+                const float v = acc[t][r] + bias;
+                g.Y[(size_t)gn * g.ldy + col] = g.relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+    }
+}
+
 #include "mopoe_latent.inc"
 
 // Scalars of the step from the row tiles' partial sums, in a fixed order
@@ -1004,6 +1118,13 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s) 
     LinArgs la = la_in;
     const int kp = round_up(max_k < kEncKChunk ? max_k : kEncKChunk, 16);
     const size_t lds = ((size_t)kRows * (kp + 4) + kLinRedFloats) * sizeof(float);
+    if (la.n >= kLinBigRows) {
+        ProfScope ps(MOPOE_KERNEL_LINEAR, s);
+        hipLaunchKernelGGL(k_linear_big,
+                           dim3(cdiv(max_cols, kBigCols), cdiv(la.n, kBigRows), la.ngroups),
+                           dim3(256), 0, s, la);
+        return check_launch("k_linear_big");
+    }
     // K parts per column tile: as many as it takes to put ~2 workgroups on every CU
     const int tiles = cdiv(la.n, kRows) * la.ngroups;
     int ks = 1;

@@ -166,3 +166,35 @@ def test_philox_noise_is_standard_normal():
     assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
     assert abs(float((z * z2).mean())) < 0.01        # streams are independent
     assert float((z ** 4).mean()) == pytest.approx(3.0, abs=0.1)
+
+
+@pytest.mark.parametrize("n,k,ncols", [(2048, 444, 256), (2500, 7, 256), (4100, 130, 100),
+                                        (3000, 513, 70)])
+def test_large_batch_linear_tiles(n, k, ncols):
+    """Batches of 2048 rows and more go through the 64x64-tile variant of the encoder
+    layer (W staged through LDS); same contract as the small-batch kernel: float32
+    fmaf chains, so a float64 reference is met at float32 rounding."""
+    from importlib import import_module
+    ops = import_module("2022_cambroise_interpret_multivae_amd.ops")
+    g = torch.Generator().manual_seed(n + k)
+    x = torch.randn(n, k, generator=g)
+    w = torch.randn(ncols, k, generator=g) / k ** 0.5
+    b = torch.randn(ncols, generator=g)
+    want = torch.relu(x.double() @ w.double().t() + b.double())
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda(), relu=True)
+    rep = Report("linear %dx%dx%d" % (n, k, ncols))
+    rep.close("y", got, want, 2e-5, 2e-5)
+    rep.finish()
+    # and inside the forward: a 2304-row batch against the oracle
+    cfg = mo.Config(["clinical", "rois"], [7, 444], [3, 20])
+    if (n, k) == (2048, 444):
+        from hip_util import make_engine, compare_forward
+        spec, eng = make_engine(cfg)
+        xb = mo.make_inputs(cfg.names, cfg.input_dim, 2304, seed=5)
+        params = mo.init_params(cfg, 0)
+        out = mo.forward(params, cfg, xb, mo.Noise(tape=[]), sample_latents=False)
+        plan, ws = eng.forward(xb, sample=False)
+        torch.cuda.synchronize()
+        rep2 = Report("forward N=2304")
+        compare_forward(rep2, spec, eng, plan, ws, out)
+        rep2.finish()
