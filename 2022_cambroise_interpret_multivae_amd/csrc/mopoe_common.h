@@ -71,7 +71,7 @@ struct alignas(64) FuseJob {
     int mod, slot, src, stream;
     int zj, ldz, epsc, stdc;     // LDS: z tile and its ld, content eps / std [R*D]
     int epss, stds, gzj, gz_off; // LDS: style eps / std [R*sd], kept g_z, column in the slabs
-    int sd, ldzg, pad0, pad1;    // style dim of the modality, ld of z[m] in HBM
+    int sd, ldzg, chunks, pad1;  // style dim of the modality, ld of z[m] in HBM, g_z slabs
 };
 struct alignas(32) FuseSub {
     uint32_t desc;       // avail | kind << 1 | mask << 3 | E << 8 | members (3 bits each) << 11
@@ -89,7 +89,7 @@ struct alignas(64) DecJob {   // decoder stages (x_hat and d loss / d z), per de
     int gx, gz_off, off_wd, off_bd;  // LDS: g_xhat tile, column in the g_z slabs; parameters
     int off_lvo, lvo_part, nblk_z, nblk_d;  // lvo_part: this job's slot in a group's partials
     float nll_coef;
-    int pad0, pad1, pad2;
+    int chunks, per, pad2;           // g_z slabs of this job, K blocks of 16 per slab
     float* loc;                      // buffers.loc[mod], buffers.g_xhat[mod]
     float* g_xhat;
     int pad3[8];
@@ -110,7 +110,8 @@ struct LatentLds {
     int xs[MOPOE_MAX_MODS];      // R0: input tile             [16][ld_x]
     int gx[MOPOE_MAX_MODS];      // g_xhat tile (= xs when decoded once)
     int xs_early;                // x tiles have their own area and are loaded at kernel start
-    int gzp, ld_gzp, gz_chunks;  // R0: g_z partials           [chunks][16][ld_gzp]
+    int gzp, ld_gzp, gz_chunks;  // R0: g_z partials           [max chunks][16][ld_gzp]
+    int job_chunks[MOPOE_MAX_JOBS], job_per[MOPOE_MAX_JOBS];  // slabs / blocks per slab
     int klt;                     // overlays gzp: KL terms     [subsets][16*D], then styles
     int klt_style[MOPOE_MAX_MODS];
     int heads[MOPOE_MAX_MODS];   // encoder outputs            [16][ld_heads]
@@ -137,7 +138,7 @@ struct LatentLds {
     int sl_begin[MOPOE_MAX_MODS + 1];  // element-wise slots: [0] content slots, then
                                        // the end of each modality's style slots
     int s3_begin[MOPOE_MAX_JOBS + 1];  // decoder units (64 columns), all jobs
-    int s4_begin[MOPOE_MAX_JOBS + 1];  // g_z units (64 columns x gz_chunks), all jobs
+    int s4_begin[MOPOE_MAX_JOBS + 1];  // g_z units (64 columns x the job's slabs), all jobs
     int pass_end[MOPOE_MAX_JOBS];      // one past the last job of the pass starting here
     int pres_mod[MOPOE_MAX_MODS];      // k-th present modality
     int npres;
@@ -193,10 +194,20 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
     int xrel[MOPOE_MAX_MODS];
     for (int i = 0; i < MOPOE_MAX_MODS; ++i) xrel[i] = i < m.num_mods ? L.xs[i] : 0;
     for (int option = 0;; ++option) {
-        const int early_of[6] = {1, 1, 0, 0, 0, 0};
-        const int chunks_of[6] = {8, 4, 8, 4, 2, 1};
+        // the dL/dz GEMM splits its reduction axis (d_m, in blocks of 16) into slabs
+        // of >= 3 blocks (one round of loads per wave), at most `cap` slabs per job
+        const int early_of[8] = {1, 1, 1, 0, 0, 0, 0, 0};
+        const int cap_of[8] = {12, 8, 4, 12, 8, 4, 2, 1};
         L.xs_early = early_of[option];
-        L.gz_chunks = chunks_of[option];
+        L.gz_chunks = 1;
+        for (int j = 0; j < MOPOE_MAX_JOBS; ++j) {
+            const int nb = j < st.num_jobs ? round_up(m.input_dim[st.job_mod[j]], 16) / 16 : 1;
+            int c = cdiv(nb, 3);
+            if (c > cap_of[option]) c = cap_of[option];
+            L.job_chunks[j] = c;
+            L.job_per[j] = cdiv(nb, c);
+            if (c > L.gz_chunks) L.gz_chunks = c;
+        }
         int gz = L.gz_chunks * R * L.ld_gzp;
         if (gz < klt_rel) gz = klt_rel;
         int off;
@@ -255,7 +266,7 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
         off += waves * kStatStride;
         L.total = off;
         fits = off * 4 <= 160 * 1024;
-        if (fits || option == 5) break;
+        if (fits || option == 7) break;
     }
     {
         int t = 0, sl = cdiv(R * D, kWave);
@@ -286,7 +297,7 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
             L.s4_begin[j] = u4;
             if (j < st.num_jobs) {
                 u3 += cdiv(m.input_dim[st.job_mod[j]], 16 * L.s3_nt);
-                u4 += cdiv(z_dim(m, st.job_mod[j]), 64) * L.gz_chunks;
+                u4 += cdiv(z_dim(m, st.job_mod[j]), 64) * L.job_chunks[j];
             }
         }
         for (int j = 0; j < MOPOE_MAX_JOBS; ++j) {
@@ -325,7 +336,8 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
         f.gz_off = L.gz_off[j];
         f.sd = m.style_dim[i];
         f.ldzg = ldz_glb(m, i);
-        f.pad0 = f.pad1 = 0;
+        f.chunks = L.job_chunks[j];
+        f.pad1 = 0;
         if (on && st.job_src[j] < 0) L.joint_jobs |= 1u << j;
     }
     for (int k = 0; k < MOPOE_MAX_SUBSETS; ++k) {
@@ -369,7 +381,9 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
         f.nblk_z = round_up(f.zd, 16) / 16;
         f.nblk_d = round_up(f.dm, 16) / 16;
         f.nll_coef = on ? st.job_nll_coef[j] : 0.f;
-        f.pad0 = f.pad1 = f.pad2 = 0;
+        f.chunks = L.job_chunks[j];
+        f.per = L.job_per[j];
+        f.pad2 = 0;
         f.loc = f.g_xhat = nullptr;   // latent_bind()
         for (int k = 0; k < 8; ++k) f.pad3[k] = 0;
     }
