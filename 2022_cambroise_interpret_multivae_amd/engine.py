@@ -69,6 +69,7 @@ class MoPoEEngine:
         self.exp_avg = torch.zeros(P, **f)
         self.exp_avg_sq = torch.zeros(P, **f)
         self.counters = torch.zeros(16, dtype=torch.int32, device=self.device)
+        self.device = self.params.device   # with its index: cheap `is it already there` tests
         self.views = spec.param_views(self.params)
         self.grad_views = spec.param_views(self.grads)
         self.seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1)
@@ -166,7 +167,9 @@ class MoPoEEngine:
         x = OrderedDict()
         n = None
         for name, v in batch.items():
-            t = v.to(self.device, dtype=torch.float32).contiguous()
+            t = v
+            if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+                t = v.to(self.device, dtype=torch.float32).contiguous()
             m = self.spec.names.index(name)
             if t.dim() != 2 or t.shape[1] != self.spec.input_dim[m]:
                 raise ValueError("batch[%r] has shape %s, expected (N, %d)" % (

@@ -42,25 +42,81 @@ class _FusedLoss(torch.autograd.Function):
         return None, None, None
 
 
+class _Lazy(dict):
+    """A dict filled on first use.  The training loop only reads `results`,
+    `log_probs` and `klds` when it logs; building the ~40 tensor views and the
+    Normal objects of BaseMMVae.forward's dict costs more host time than the step
+    takes on the GPU.  (As with the eager dict, the entries are views of the step's
+    workspace: read them before the next training step overwrites it.)"""
+
+    def __init__(self, build):
+        super().__init__()
+        self._build = build
+
+    def _fill(self):
+        if self._build is not None:
+            build, self._build = self._build, None
+            dict.update(self, build())
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._fill()
+        return dict.__len__(self)
+
+    def __contains__(self, k):
+        self._fill()
+        return dict.__contains__(self, k)
+
+    def __repr__(self):
+        self._fill()
+        return dict.__repr__(self)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def get(self, k, default=None):
+        self._fill()
+        return dict.get(self, k, default)
+
+
 def basic_routine_epoch(exp, model_idx, batch):
     """reference run_epochs.py:73-135"""
     model = exp.models
     if exp.flags.num_models > 1:
         model = model[model_idx]
     batch_d = batch[0]
+    dev = model.engine.device
     for m_key in batch_d.keys():                     # run_epochs.py:85-86
-        batch_d[m_key] = batch_d[m_key].to(exp.flags.device).float()
+        t = batch_d[m_key]
+        if t.device != dev or t.dtype != torch.float32:
+            batch_d[m_key] = t.to(dev).float()
     eng = model.engine
     if torch.is_grad_enabled():
         plan, ws = eng.train_step(batch_d, apply_adam=False)
-        sc = eng.scalars(plan, ws)
-        total_loss = _FusedLoss.apply(model._anchor, model, sc["total_loss"])
+        total_loss = _FusedLoss.apply(model._anchor, model, ws.stats[L.STAT_TOTAL_LOSS])
     else:
         plan, ws = eng.forward(batch_d, sample=True, loss=True, fresh=True)
-        sc = eng.scalars(plan, ws)
-        total_loss = sc["total_loss"]
-    return {"results": eng.results(plan, ws), "log_probs": sc["log_probs"],
-            "total_loss": total_loss, "klds": sc["klds"]}
+        total_loss = ws.stats[L.STAT_TOTAL_LOSS]
+    sc = _Lazy(lambda: eng.scalars(plan, ws))
+    return {"results": _Lazy(lambda: eng.results(plan, ws)),
+            "log_probs": _Lazy(lambda: sc["log_probs"]),
+            "total_loss": total_loss, "klds": _Lazy(lambda: sc["klds"])}
 
 
 def train(model_idx, epoch, exp, tb_logger):
