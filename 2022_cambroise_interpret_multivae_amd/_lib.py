@@ -13,7 +13,7 @@ MAX_SUBSETS = 31
 MAX_JOBS = 10
 HIDDEN = 256
 ROWS = 16
-ABI_VERSION = 1
+ABI_VERSION = 4
 
 SUB_POE, SUB_POE_PRIOR, SUB_SLICES = 0, 1, 2
 JOINT_MIXTURE, JOINT_MEAN, JOINT_EXPERT = 0, 1, 2

@@ -28,12 +28,12 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 1
+#define MOPOE_ABI_VERSION 4
 #define MOPOE_MAX_MODS 5      /* modalities                                   */
 #define MOPOE_MAX_SUBSETS 31  /* 2^MAX_MODS - 1 non-empty subsets             */
 #define MOPOE_MAX_JOBS 10     /* decoder passes: 1 joint + 1 unimodal per mod */
 #define MOPOE_HIDDEN 256      /* networks/networks.py:14,50 (hard-coded)      */
-#define MOPOE_ROWS 16         /* batch rows per workgroup tile (one MFMA M)   */
+#define MOPOE_ROWS 16         /* batch rows per MFMA tile; a row group has <= 16 */
 
 #define MOPOE_ERR_ARG (-1)
 #define MOPOE_ERR_HIP (-2)
