@@ -94,3 +94,25 @@ def test_group_rows_is_validated():
     x = {"clinical": torch.zeros(20, 7).cuda(), "rois": torch.zeros(20, 444).cuda()}
     with pytest.raises(ValueError):
         eng.forward(x, group_rows=7)
+
+
+def test_folded_repeats_through_the_large_batch_encoder_kernel():
+    """64 repeats of 40 rows = 2560 rows: the folded launch takes the 64x64-tile
+    encoder kernel (with the row gather), a single 40-row forward the small-batch one.
+    Different summation orders, same float32 tolerance."""
+    from importlib import import_module
+    daa = import_module("2022_cambroise_interpret_multivae_amd.daa")
+    exp = make_experiment(_cfg(), "cuda")
+    model = exp.models
+    model.load_state_dict(mo.init_params(_cfg(), 0))
+    n, M = 40, 64
+    g = torch.Generator().manual_seed(9)
+    data = {"clinical": torch.randn(n, 7, generator=g).cuda(),
+            "rois": torch.randn(n, 444, generator=g).cuda()}
+    rec = daa.repeated_reconstructions(model, data, M, sample_latents=False)
+    one = model(data, sample_latents=False)["rec"]
+    rep = Report("folded 2560 rows vs one forward")
+    for name in data:
+        for i in (0, 17, M - 1):
+            rep.close("%s/rep%d" % (name, i), rec[name][0][i], one[name].loc, *TOL["loc"])
+    rep.finish()
