@@ -24,7 +24,7 @@ STAT_KLD_SUBSET = 2
 STAT_KLD_STYLE = 2 + MAX_SUBSETS
 STAT_NLL = STAT_KLD_STYLE + MAX_MODS
 NUM_STATS = STAT_NLL + MAX_JOBS
-KERNEL_NAMES = ("k_linear", "k_latent", "k_wgrad", "k_adam", "k_finalize")
+KERNEL_NAMES = ("k_linear", "k_latent", "k_wgrad", "k_adam", "k_finalize", "k_fused")
 
 _i32 = C.c_int32
 _u8 = C.c_uint8

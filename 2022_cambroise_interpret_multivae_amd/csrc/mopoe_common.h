@@ -547,6 +547,11 @@ DEV float ldg(rsrc_t r, uint32_t byte_off) {
 DEV f32x4 ldg4(rsrc_t r, uint32_t byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
+// 16-byte load past the L1 (sc1): for data another workgroup of the SAME launch wrote
+// (write-through) -- this CU's L1 is never refreshed by other CUs' stores
+DEV f32x4 ldg4_sc1(rsrc_t r, uint32_t byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
 // 16-byte WRITE-THROUGH store (sc1): the line does not stay dirty in the XCD's L2, so
 // it is on its way to memory while the kernel still runs instead of being flushed when
 // the kernel ends (the consumer is the next kernel, on any XCD, through memory anyway).

@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -30,6 +31,8 @@ constexpr int kLatentThreads = 1024;
 constexpr int kLatentWaves = kLatentThreads / kWave;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 constexpr float kPoeEps = 1e-8f;
+constexpr int kHandoffSpins = 1 << 18;  // bounded wait of a consumer group (~0.3 s)
+constexpr int kHandoffWord = 63;        // word of a group's partial slab used as its flag
 
 // Diagnostic build only (-DMOPOE_STAMPS, libmopoe_hip_stamps.so): thread 0 of
 // block 0 parks the low words of s_memrealtime [100 MHz] and s_memtime [shader
@@ -40,7 +43,7 @@ constexpr float kPoeEps = 1e-8f;
 #ifdef MOPOE_STAMPS
 #define STAMP(buf, i)                                                                  \
     do {                                                                               \
-        if (blockIdx.x == 0 && threadIdx.x == 0) {                                     \
+        if (stamp_blk && threadIdx.x == 0) {                                          \
             stamp_lds[(i) * kStatStride + 48] =                                        \
                 __uint_as_float((unsigned)__builtin_amdgcn_s_memrealtime());           \
             stamp_lds[(i) * kStatStride + 49] =                                        \
@@ -49,7 +52,7 @@ constexpr float kPoeEps = 1e-8f;
     } while (0)
 #define STAMPW(buf, i, w)                                                              \
     do {                                                                               \
-        if (blockIdx.x == 0 && threadIdx.x == (w) * 64) {                              \
+        if (stamp_blk && threadIdx.x == (w) * 64) {                                   \
             stamp_lds[(i) * kStatStride + 48] =                                        \
                 __uint_as_float((unsigned)__builtin_amdgcn_s_memrealtime());           \
             stamp_lds[(i) * kStatStride + 49] =                                        \
@@ -58,7 +61,7 @@ constexpr float kPoeEps = 1e-8f;
     } while (0)
 #define STAMP_FLUSH(stats_ptr, n)                                                      \
     do {                                                                               \
-        if (blockIdx.x == 0 && threadIdx.x < 2 * (n))                                  \
+        if (stamp_blk && threadIdx.x < 2 * (n))                                       \
             (stats_ptr)[64 + threadIdx.x] =                                            \
                 stamp_lds[(threadIdx.x >> 1) * kStatStride + 48 + (threadIdx.x & 1)];  \
     } while (0)
@@ -91,7 +94,7 @@ struct KArgs {
     mopoe_buffers buf;
     LatentLds lds;  // carve-up of k_latent's LDS, computed on the host
 };
-static_assert(sizeof(KArgs) <= 8192, "kernel argument block too large");  // (12 KB launches fine: tools/kernarg_probe.hip)
+static_assert(sizeof(KArgs) <= 7680, "kernel argument block too large");  // (12 KB launches fine: tools/kernarg_probe.hip)
 
 DEV int src_row(const mopoe_buffers& buf, int m, int gn) {
     return buf.row_index[m] ? buf.row_index[m][gn] : gn;
@@ -466,6 +469,170 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a_by_value) {
 }
 
 #include "mopoe_latent.inc"
+
+// ---------------------------------------------------------------------------
+// k_fused: encoder layer AND the per-sample chain in one launch, for small training
+// batches.  Blocks [0, nlin) are the encoder layer (one 16-row x 64-column tile of one
+// modality each, K cut over the four waves of a column tile), blocks [nlin, ..) are
+// the row groups of k_latent.  A kernel boundary between the two costs ~2 us on the
+// device plus the ~3.5 us the first loads of a fresh kernel take; here a row group
+// has its weight fragments, x tiles and descriptors in flight while its rows of h are
+// being computed, and picks them up one memory round trip after the last producer's
+// flag.  Producers never wait for anything and sit at the LOW block indices, so the
+// wait of a consumer cannot deadlock whatever the residency (and it is bounded).
+// ---------------------------------------------------------------------------
+struct FArgs {
+    KArgs ka;      // first: latent_body prefetches sizeof(KArgs) bytes of the segment
+    LinArgs la;
+    int32_t nlin;        // encoder-layer blocks
+    int32_t row_tiles;   // 16-row tiles = row groups
+};
+
+DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt, int cg,
+                        int tid, int lane, int wave, int32_t* flag) {
+    constexpr int KS = 4, CH = 8, kStage = 2;
+    const int N = a.n, K = g.K;
+    const bool vec = K % 4 == 0;
+    const int n0 = rt * kRows;
+    const int tile = wave >> 2, part = wave & 3;
+    const int j0 = (cg * 4 + tile) * 16;
+    int* rowsel = reinterpret_cast<int*>(lds);
+    float* xt = lds + kRows;
+    const bool gather = g.rows != nullptr;
+    if (gather) {
+        if (tid < kRows) rowsel[tid] = g.rows[min(n0 + tid, N - 1)];
+        __syncthreads();
+    }
+    const rsrc_t xr = make_rsrc_max(g.X);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    for (int kc0 = 0; kc0 < K; kc0 += kEncKChunk) {
+        const int Kc = min(kEncKChunk, K - kc0);
+        const int Kp = round_up(Kc, 16);
+        const int ldx = Kp + 4;
+        const int q4 = Kp / 4;
+        const int kend = j0 < g.ncols ? Kp : 0;
+        const rsrc_t wr = make_rsrc(g.W + kc0, (size_t)g.ncols * K * sizeof(float));
+        auto load_w = [&](int i0, f32x4 (&b)[CH]) __attribute__((always_inline)) {
+            if (vec) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c)  // k >= Kc is out of range -> 0
+                    b[c] = glb_b4_nt<true>(wr, K, Kc, j0, 16 * (part + KS * (i0 + c)), lane);
+            } else {
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    b[c] = glb_b4_nt<false>(wr, K, Kc, j0, 16 * (part + KS * (i0 + c)), lane);
+            }
+        };
+        f32x4 b[CH];
+        if (kc0 > 0) __syncthreads();
+        for (int s0 = 0; s0 < kRows * q4; s0 += kStage * kLatentThreads) {
+            f32x4 v[kStage];
+#pragma unroll
+            for (int i = 0; i < kStage; ++i) {
+                const int s = s0 + i * kLatentThreads + tid;
+                const int r = min(s / q4, kRows - 1), k = (s - (s / q4) * q4) * 4;
+                const bool rv = (s < kRows * q4) & (n0 + r < N);
+                const int row = gather ? rowsel[r] : min(n0 + r, N - 1);
+                const uint32_t base = (uint32_t)(row * g.ldx + kc0 + k) * 4u;
+                if (vec) {
+                    v[i] = ldg4(xr, guard(base, rv & (k < Kc)));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[i][e] = ldg(xr, guard(base + 4u * e, rv & (k + e < Kc)));
+                }
+            }
+            if (s0 == 0) load_w(0, b);  // behind the x loads (loads return in order)
+#pragma unroll
+            for (int i = 0; i < kStage; ++i) {
+                const int s = s0 + i * kLatentThreads + tid;
+                if (s < kRows * q4) {
+                    const int r = s / q4, k = (s - r * q4) * 4;
+                    *reinterpret_cast<f32x4*>(xt + r * ldx + k) = v[i];
+                }
+            }
+        }
+        __syncthreads();
+        for (int i0 = 0; 16 * (part + KS * i0) < kend; i0 += CH) {
+            f32x4 bn[CH];
+            const bool more = 16 * (part + KS * (i0 + CH)) < kend;  // wave-uniform
+            if (more) load_w(i0 + CH, bn);
+            f32x4 av[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int k = 16 * (part + KS * (i0 + c));
+                av[c] = lds_a4(xt, ldx, k < kend ? k : 0, lane);
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                acc = mfma_16x16x4(av[c][0], b[c][0], acc);
+                acc2 = mfma_16x16x4(av[c][1], b[c][1], acc2);
+                acc = mfma_16x16x4(av[c][2], b[c][2], acc);
+                acc2 = mfma_16x16x4(av[c][3], b[c][3], acc2);
+            }
+            if (more) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) b[c] = bn[c];
+            }
+        }
+    }
+    acc += acc2;
+    // parts 1..3 hand their partial tiles over through LDS (behind the x tile)
+    float* red = xt + kRows * (round_up(min(K, kEncKChunk), 16) + 4);
+    if (part > 0) *reinterpret_cast<f32x4*>(red + ((tile * 3 + part - 1) * kWave + lane) * 4) = acc;
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+        for (int p = 1; p < KS; ++p)  // fixed order
+            acc += *reinterpret_cast<const f32x4*>(red + ((tile * 3 + p - 1) * kWave + lane) * 4);
+        const int col = j0 + (lane & 15);
+        if (col < g.ncols) {
+            const float bias = g.b ? g.b[col] : 0.f;
+            const rsrc_t yr = make_rsrc(g.Y, (size_t)N * g.ldy * sizeof(float));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gn = n0 + 4 * (lane >> 4) + r;
+                const float v = acc[r] + bias;
+                // written through (sc1): the consumer group reads it from memory
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    __builtin_bit_cast(uint32_t, g.relu ? fmaxf(v, 0.f) : v), yr,
+                    guard((uint32_t)(gn * g.ldy + col) * 4u, gn < N), 0, 16);
+            }
+        }
+    }
+    // hand-off: every storing wave drains its stores, then ONE lane signals
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value) {
+    (void)f_by_value;  // read in place (see k_latent)
+    const FArgs& f = *(const FArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x;
+    const int stride = f.ka.lds.part_stride;
+    if (b < f.nlin) {
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const LinArgs& a = f.la;
+        if (b == 0 && tid == 0) {
+            const int t = a.counters[0] + 1;  // training step number (Adam, Philox)
+            a.counters[0] = t;
+            if (a.publish) {
+                *reinterpret_cast<AdamCoef*>(a.counters + kCoefBase) = adam_coef(a.adam, t);
+                a.counters[kCoefTag] = t;
+            }
+        }
+        const int cg = b & 3, rt = (b >> 2) % f.row_tiles, z = (b >> 2) / f.row_tiles;
+        int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * stride + kHandoffWord);
+        linear_block16(a, a.g[z], lds, rt, cg, tid, lane, wave, flag);
+        return;
+    }
+    const int grp = b - f.nlin;
+    int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)grp * stride + kHandoffWord);
+    latent_body<true>(f.ka, lds, grp, flag, 4 * f.la.ngroups);
+}
 
 // Scalars of the step from the row tiles' partial sums, in a fixed order
 // (run_epochs.py:89-128, mm_div.py:92-111, kl_div.py:7-14).  One block of 256
@@ -1138,6 +1305,9 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s) 
     return check_launch("k_linear");
 }
 
+// MOPOE_NO_FUSE=1 keeps the encoder layer and the per-sample chain in two launches
+static const bool g_no_fuse = getenv("MOPOE_NO_FUSE") != nullptr;
+
 int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) {
     const mopoe_model& mdl = ka.mdl;
     LinArgs la;
@@ -1163,11 +1333,37 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         g.ldy = kHid;
         g.relu = 1;
     }
-    if (int rc = launch_linear(la, maxd, kHid, s)) return rc;
-
-    const int lds = ka.lds.total * (int)sizeof(float);
+    int lds = ka.lds.total * (int)sizeof(float);
     if (lds > 160 * 1024)
         return fail(MOPOE_ERR_ARG, "model exceeds the 160 KiB LDS tile budget%s");
+    // Small training batches: encoder layer and per-sample chain in ONE launch
+    // (k_fused).  Needs full 16-row groups and the whole grid resident at once to pay.
+    const int row_tiles = cdiv(ka.st.n, kRows);
+    const int nlin = 4 * row_tiles * la.ngroups;
+    if (ka.st.backward && ka.lds.rows == kRows && nlin + row_tiles <= 256 && !g_no_fuse) {
+        static thread_local int lds_opted_f = 0;
+        const int kp = round_up(maxd < kEncKChunk ? maxd : kEncKChunk, 16);
+        const int lin_lds = (kRows + kRows * (kp + 4) + 12 * kWave * 4) * (int)sizeof(float);
+        if (lin_lds > lds) lds = lin_lds;
+        if (lds > 64 * 1024 && lds > lds_opted_f) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return fail(MOPOE_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            lds_opted_f = lds;
+        }
+        FArgs fa;
+        fa.ka = ka;
+        fa.la = la;
+        fa.nlin = nlin;
+        fa.row_tiles = row_tiles;
+        {
+            ProfScope ps(MOPOE_KERNEL_FUSED, s);
+            hipLaunchKernelGGL(k_fused, dim3(nlin + row_tiles), dim3(kLatentThreads), (size_t)lds, s, fa);
+        }
+        return check_launch("k_fused");
+    }
+    if (int rc = launch_linear(la, maxd, kHid, s)) return rc;
+
     static thread_local int lds_opted = 0;
     if (lds > 64 * 1024 && lds > lds_opted) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_latent),

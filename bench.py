@@ -83,6 +83,10 @@ def kernel_models(spec, n, fused_adam):
         wbytes += f * 6 * P
     out["k_wgrad"] = dict(flops=2.0 * n * (HIDDEN * d + HIDDEN * nh + dz),
                           bytes=wbytes)
+    # encoder layer + per-sample chain in one launch (small training batches): h is
+    # written (for the weight gradients) and read back by the row groups all the same
+    out["k_fused"] = dict(flops=out["k_linear"]["flops"] + out["k_latent"]["flops"],
+                          bytes=out["k_linear"]["bytes"] + out["k_latent"]["bytes"])
     out["k_adam"] = dict(flops=0.0, bytes=f * 7 * P)
     out["k_finalize"] = dict(flops=0.0, bytes=0.0)
     return out

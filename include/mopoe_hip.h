@@ -209,7 +209,8 @@ typedef struct mopoe_adam {
 #define MOPOE_KERNEL_WGRAD 2
 #define MOPOE_KERNEL_ADAM 3
 #define MOPOE_KERNEL_FINALIZE 4
-#define MOPOE_NUM_KERNELS 5
+#define MOPOE_KERNEL_FUSED 5   /* encoder layer + per-sample chain in one launch */
+#define MOPOE_NUM_KERNELS 6
 int mopoe_profile_enable(int enable);
 int mopoe_profile_read(int32_t* count, float* total_ms);
 

@@ -13,7 +13,7 @@ cnt = {}
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f, newline="")):
         name = row["Kernel_Name"]
-        short = next((k for k in ("k_linear", "k_latent", "k_wgrad") if k + "(" in name or k + "<" in name), None)
+        short = next((k for k in ("k_linear", "k_latent", "k_wgrad", "k_fused") if k + "(" in name or k + "<" in name), None)
         if not short:
             continue
         key = (short, row["Counter_Name"])

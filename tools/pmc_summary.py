@@ -22,7 +22,7 @@ def per_kernel(path, counter):
                     continue
                 name = row["Kernel_Name"]
                 short = next((k for k in ("k_linear", "k_latent", "k_wgrad", "k_adam",
-                                          "k_finalize") if k + "(" in name or k + "<" in name),
+                                          "k_finalize", "k_fused") if k + "(" in name or k + "<" in name),
                              None)
                 if short is None:
                     continue
