@@ -192,7 +192,11 @@ typedef struct mopoe_buffers {
     float* g_heads[MOPOE_MAX_MODS];      /* (n, nh_m)                          */
     float* g_pre[MOPOE_MAX_MODS];        /* (n, 256)     d loss / d pre-relu   */
     float* partials;                     /* (mopoe_row_groups(model, step),
-                                            mopoe_partials_stride(model))      */
+                                            mopoe_partials_stride(model)); ZERO it
+                                            once after allocating: word 63 of a
+                                            slab is the row group's hand-off flag
+                                            in the fused launch, left at zero by
+                                            every call                          */
 } mopoe_buffers;
 
 typedef struct mopoe_adam {
