@@ -222,6 +222,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(ws.stats[0].item())
+    if int(eng.counters[2].item()) != 0:
+        sys.exit("a hand-off inside the fused launch timed out")
     if not args.no_log_copy:   # the host ring must have received the same scalar
         host = float(log_ring[(args.warmup + args.steps - 1) % 8][0])
         if host != loss:

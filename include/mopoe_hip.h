@@ -165,6 +165,8 @@ typedef struct mopoe_buffers {
     float* exp_avg;                      /* (num_floats)  Adam m               */
     float* exp_avg_sq;                   /* (num_floats)  Adam v               */
     int32_t* counters;                   /* (16) [0] steps begun, [1] steps done,
+                                            [2] != 0: a hand-off inside the fused
+                                            launch timed out (results invalid),
                                             [3..10] Adam coefficients of step [0] */
 
     const float* x[MOPOE_MAX_MODS];      /* (rows, d_m) input, ld = d_m        */
