@@ -1305,9 +1305,14 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s) 
     return check_launch("k_linear");
 }
 
-// MOPOE_NO_FUSE=1 keeps the encoder layer and the per-sample chain in two launches
-static const bool g_no_fuse = getenv("MOPOE_NO_FUSE") != nullptr;
-static const int g_fuse_blocks = getenv("MOPOE_FUSE_BLOCKS") ? atoi(getenv("MOPOE_FUSE_BLOCKS")) : 256;
+// MOPOE_NO_FUSE=1 keeps the encoder layer and the per-sample chain in two launches;
+// MOPOE_FUSE_BLOCKS caps the grid the fused launch is used for.  Read per call (two
+// getenv), so a test can compare the two forms inside one process.
+static bool no_fuse() { return getenv("MOPOE_NO_FUSE") != nullptr; }
+static int fuse_blocks() {
+    const char* v = getenv("MOPOE_FUSE_BLOCKS");
+    return v ? atoi(v) : 256;
+}
 
 int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) {
     const mopoe_model& mdl = ka.mdl;
@@ -1341,7 +1346,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     // (k_fused).  Needs full 16-row groups and the whole grid resident at once to pay.
     const int row_tiles = cdiv(ka.st.n, kRows);
     const int nlin = 4 * row_tiles * la.ngroups;
-    if (ka.st.backward && ka.lds.rows == kRows && nlin + row_tiles <= g_fuse_blocks && !g_no_fuse) {
+    if (ka.st.backward && ka.lds.rows == kRows && nlin + row_tiles <= fuse_blocks() && !no_fuse()) {
         static thread_local int lds_opted_f = 0;
         const int kp = round_up(maxd < kEncKChunk ? maxd : kEncKChunk, 16);
         const int lin_lds = (kRows + kRows * (kp + 4) + 12 * kWave * 4) * (int)sizeof(float);
