@@ -509,7 +509,6 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
         const int Kc = min(kEncKChunk, K - kc0);
         const int Kp = round_up(Kc, 16);
         const int ldx = Kp + 4;
-        const int q4 = Kp / 4;
         const int kend = j0 < g.ncols ? Kp : 0;
         const rsrc_t wr = make_rsrc(g.W + kc0, (size_t)g.ncols * K * sizeof(float));
         auto load_w = [&](int i0, f32x4 (&b)[CH]) __attribute__((always_inline)) {
@@ -525,14 +524,18 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
         };
         f32x4 b[CH];
         if (kc0 > 0) __syncthreads();
-        for (int s0 = 0; s0 < kRows * q4; s0 += kStage * kLatentThreads) {
+        // staging: wave w owns row w of the tile (16 waves = 16 rows), its lanes
+        // consecutive float4 of it -- no index arithmetic before the loads go out,
+        // one fully coalesced kilobyte per wave-instruction
+        static_assert(kLatentWaves == kRows && kEncKChunk <= kStage * 4 * kWave, "one row per wave");
+        {
             f32x4 v[kStage];
+            const int r = wave;
+            const bool rv = n0 + r < N;
+            const int row = gather ? rowsel[r] : min(n0 + r, N - 1);
 #pragma unroll
             for (int i = 0; i < kStage; ++i) {
-                const int s = s0 + i * kLatentThreads + tid;
-                const int r = min(s / q4, kRows - 1), k = (s - (s / q4) * q4) * 4;
-                const bool rv = (s < kRows * q4) & (n0 + r < N);
-                const int row = gather ? rowsel[r] : min(n0 + r, N - 1);
+                const int k = (i * kWave + lane) * 4;
                 const uint32_t base = (uint32_t)(row * g.ldx + kc0 + k) * 4u;
                 if (vec) {
                     v[i] = ldg4(xr, guard(base, rv & (k < Kc)));
@@ -542,14 +545,11 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
                         v[i][e] = ldg(xr, guard(base + 4u * e, rv & (k + e < Kc)));
                 }
             }
-            if (s0 == 0) load_w(0, b);  // behind the x loads (loads return in order)
+            load_w(0, b);  // behind the x loads (loads return in order)
 #pragma unroll
             for (int i = 0; i < kStage; ++i) {
-                const int s = s0 + i * kLatentThreads + tid;
-                if (s < kRows * q4) {
-                    const int r = s / q4, k = (s - r * q4) * 4;
-                    *reinterpret_cast<f32x4*>(xt + r * ldx + k) = v[i];
-                }
+                const int k = (i * kWave + lane) * 4;
+                if (k < Kp) *reinterpret_cast<f32x4*>(xt + r * ldx + k) = v[i];
             }
         }
         __syncthreads();
@@ -577,27 +577,34 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
         }
     }
     acc += acc2;
-    // parts 1..3 hand their partial tiles over through LDS (behind the x tile)
+    // All four K parts park their partial tiles in LDS as [row][column] (behind the x
+    // tile); 256 threads then add the parts in fixed order, four consecutive columns
+    // each, and write h with ONE 16-byte write-through store (the consumer group reads
+    // it from memory; 4-byte write-through stores cost several times more per byte).
+    constexpr int kLdR = 64 + 4;
     float* red = xt + kRows * (round_up(min(K, kEncKChunk), 16) + 4);
-    if (part > 0) *reinterpret_cast<f32x4*>(red + ((tile * 3 + part - 1) * kWave + lane) * 4) = acc;
+    {
+        const int c16 = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            red[(part * kRows + 4 * q + r) * kLdR + 16 * tile + c16] = acc[r];
+    }
     __syncthreads();
-    if (part == 0) {
+    if (tid < 256) {
+        const int row = tid >> 4, c4 = (tid & 15) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(red + row * kLdR + c4);
 #pragma unroll
         for (int p = 1; p < KS; ++p)  // fixed order
-            acc += *reinterpret_cast<const f32x4*>(red + ((tile * 3 + p - 1) * kWave + lane) * 4);
-        const int col = j0 + (lane & 15);
-        if (col < g.ncols) {
-            const float bias = g.b ? g.b[col] : 0.f;
-            const rsrc_t yr = make_rsrc(g.Y, (size_t)N * g.ldy * sizeof(float));
+            v += *reinterpret_cast<const f32x4*>(red + (p * kRows + row) * kLdR + c4);
+        const int col = cg * 64 + c4, gn = n0 + row;
+        if (col < g.ncols && gn < N) {   // (ncols is a multiple of 4 here: 256)
+            if (g.b) v += *reinterpret_cast<const f32x4*>(g.b + col);
+            if (g.relu) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gn = n0 + 4 * (lane >> 4) + r;
-                const float v = acc[r] + bias;
-                // written through (sc1): the consumer group reads it from memory
-                __builtin_amdgcn_raw_buffer_store_b32(
-                    __builtin_bit_cast(uint32_t, g.relu ? fmaxf(v, 0.f) : v), yr,
-                    guard((uint32_t)(gn * g.ldy + col) * 4u, gn < N), 0, 16);
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
+            const rsrc_t yr = make_rsrc(g.Y, (size_t)N * g.ldy * sizeof(float));
+            stg4_wt(yr, (uint32_t)(gn * g.ldy + col) * 4u, v);
         }
     }
     // hand-off: every storing wave drains its stores, then ONE lane signals
@@ -1349,7 +1356,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     if (ka.st.backward && ka.lds.rows == kRows && nlin + row_tiles <= fuse_blocks() && !no_fuse()) {
         static thread_local int lds_opted_f = 0;
         const int kp = round_up(maxd < kEncKChunk ? maxd : kEncKChunk, 16);
-        const int lin_lds = (kRows + kRows * (kp + 4) + 12 * kWave * 4) * (int)sizeof(float);
+        const int lin_lds = (kRows + kRows * (kp + 4) + 4 * kRows * 68) * (int)sizeof(float);
         if (lin_lds > lds) lds = lin_lds;
         if (lds > 64 * 1024 && lds > lds_opted_f) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused),
