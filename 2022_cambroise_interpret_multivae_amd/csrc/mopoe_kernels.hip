@@ -623,7 +623,7 @@ __global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value
         const int tid = threadIdx.x, lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const LinArgs& a = f.la;
-        if (b == 0 && tid == 0) {
+        if (a.counters && b == 0 && tid == 0) {
             const int t = a.counters[0] + 1;  // training step number (Adam, Philox)
             a.counters[0] = t;
             if (a.publish) {
@@ -1353,7 +1353,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     // (k_fused).  Needs full 16-row groups and the whole grid resident at once to pay.
     const int row_tiles = cdiv(ka.st.n, kRows);
     const int nlin = 4 * row_tiles * la.ngroups;
-    if (ka.st.backward && ka.lds.rows == kRows && nlin + row_tiles <= fuse_blocks() && !no_fuse()) {
+    if (ka.lds.rows == kRows && ka.st.group_rows == 0 && nlin + row_tiles <= fuse_blocks() && !no_fuse()) {
         static thread_local int lds_opted_f = 0;
         const int kp = round_up(maxd < kEncKChunk ? maxd : kEncKChunk, 16);
         const int lin_lds = (kRows + kRows * (kp + 4) + 4 * kRows * 68) * (int)sizeof(float);
