@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mopoe_hip.h"
 
 #define HD __host__ __device__ __forceinline__
@@ -495,10 +497,26 @@ DEV int find_seg(const int (&begin)[NSEG + 1], int u) {
     return k;
 }
 
+// Sum over the 64 lanes, the same value in every lane.  Inside a 16-lane row with DPP
+// adds (quad swaps, then the two row mirrors: an instruction each, no LDS crossbar --
+// six dependent ds_bpermute round trips cost ~500 cycles of a wave's chain), then the
+// four row sums through readlane in a fixed order.
 DEV float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+    auto dpp_add = [](float x, auto ctrl) __attribute__((always_inline)) {
+        constexpr int kCtrl = decltype(ctrl)::value;
+        const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), kCtrl, 0xF, 0xF, false);
+        return x + __builtin_bit_cast(float, y);
+    };
+    v = dpp_add(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    v = dpp_add(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    v = dpp_add(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    v = dpp_add(v, std::integral_constant<int, 0x140>{});  // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // A fragment: LDS tile [16][lda] (k contiguous).  Lane (r = l&15, q = l>>4)
