@@ -142,6 +142,7 @@ struct LatentLds {
     int s3_begin[MOPOE_MAX_JOBS + 1];  // decoder units (64 columns), all jobs
     int s4_begin[MOPOE_MAX_JOBS + 1];  // g_z units (64 columns x the job's slabs), all jobs
     int pass_end[MOPOE_MAX_JOBS];      // one past the last job of the pass starting here
+    int kl_first, kl_pool;             // waves [kl_first, kl_first + kl_pool) take the KL sums
     int pres_mod[MOPOE_MAX_MODS];      // k-th present modality
     int npres;
     int s3_nt;                         // 16-column tiles per decoder unit: 4, or 2 when the
@@ -306,6 +307,11 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
             int je = j + 1;
             while (je < st.num_jobs && st.job_stream[je] == st.job_stream[j]) ++je;
             L.pass_end[j] = j < st.num_jobs ? je : j + 1;
+        }
+        {   // the KL sums ride on the waves the first decoder pass leaves without a unit
+            const int busy = L.s3_begin[L.pass_end[0]] < waves ? L.s3_begin[L.pass_end[0]] : waves;
+            L.kl_first = busy < waves ? busy : 0;
+            L.kl_pool = waves - L.kl_first;
         }
     }
     for (int i = 0; i < MOPOE_MAX_MODS; ++i) {
