@@ -45,14 +45,11 @@ class Workspace:
                             for m in range(M)]
             self.g_pre = [torch.empty(n, L.HIDDEN, **f) for m in range(M)]
 
-
-def _ensure_partials(self, groups):
-    """`partials` holds one slab per row group of the step (plan.row_groups())."""
-    if self.partials.shape[0] < groups:
-        self.partials = torch.zeros(groups, self._stride, **self._f)
-
-
-Workspace.ensure_partials = _ensure_partials
+    def ensure_partials(self, groups):
+        """`partials` holds one slab per row group of the step (plan.row_groups()),
+        zeroed when (re)allocated: its spare words are the fused launch's hand-off flags."""
+        if self.partials.shape[0] < groups:
+            self.partials = torch.zeros(groups, self._stride, **self._f)
 
 
 class MoPoEEngine:
