@@ -486,16 +486,20 @@ struct FArgs {
     LinArgs la;
     int32_t nlin;        // encoder-layer blocks
     int32_t row_tiles;   // 16-row tiles = row groups
+    int32_t ks;          // 4: 64-column encoder tiles (K over four waves); 1: 256-column ones
 };
 
+// KS = 4: 64 columns per block, K over four waves (few row tiles); KS = 1: 256 columns
+// per block, a wave per column tile (more row tiles than the grid could hold otherwise)
+template <int KS>
 DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt, int cg,
                         int tid, int lane, int wave, int32_t* flag) {
-    constexpr int KS = 4, CH = 8, kStage = 2;
+    constexpr int CH = 8, kStage = 2, kTiles = kLatentWaves / KS, kCols = 16 * kTiles;
     const int N = a.n, K = g.K;
     const bool vec = K % 4 == 0;
     const int n0 = rt * kRows;
-    const int tile = wave >> 2, part = wave & 3;
-    const int j0 = (cg * 4 + tile) * 16;
+    const int tile = wave / KS, part = wave % KS;
+    const int j0 = (cg * kTiles + tile) * 16;
     int* rowsel = reinterpret_cast<int*>(lds);
     float* xt = lds + kRows;
     const bool gather = g.rows != nullptr;
@@ -581,7 +585,7 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
     // tile); 256 threads then add the parts in fixed order, four consecutive columns
     // each, and write h with ONE 16-byte write-through store (the consumer group reads
     // it from memory; 4-byte write-through stores cost several times more per byte).
-    constexpr int kLdR = 64 + 4;
+    constexpr int kLdR = kCols + 4;
     float* red = xt + kRows * (round_up(min(K, kEncKChunk), 16) + 4);
     {
         const int c16 = lane & 15, q = lane >> 4;
@@ -590,13 +594,13 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
             red[(part * kRows + 4 * q + r) * kLdR + 16 * tile + c16] = acc[r];
     }
     __syncthreads();
-    if (tid < 256) {
-        const int row = tid >> 4, c4 = (tid & 15) * 4;
+    if (tid < kRows * kCols / 4) {
+        const int row = tid / (kCols / 4), c4 = (tid % (kCols / 4)) * 4;
         f32x4 v = *reinterpret_cast<const f32x4*>(red + row * kLdR + c4);
 #pragma unroll
         for (int p = 1; p < KS; ++p)  // fixed order
             v += *reinterpret_cast<const f32x4*>(red + (p * kRows + row) * kLdR + c4);
-        const int col = cg * 64 + c4, gn = n0 + row;
+        const int col = cg * kCols + c4, gn = n0 + row;
         if (col < g.ncols && gn < N) {   // (ncols is a multiple of 4 here: 256)
             if (g.b) v += *reinterpret_cast<const f32x4*>(g.b + col);
             if (g.relu) {
@@ -631,14 +635,20 @@ __global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value
                 a.counters[kCoefTag] = t;
             }
         }
-        const int cg = b & 3, rt = (b >> 2) % f.row_tiles, z = (b >> 2) / f.row_tiles;
-        int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * stride + kHandoffWord);
-        linear_block16(a, a.g[z], lds, rt, cg, tid, lane, wave, flag);
+        if (f.ks == 4) {
+            const int cg = b & 3, rt = (b >> 2) % f.row_tiles, z = (b >> 2) / f.row_tiles;
+            int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * stride + kHandoffWord);
+            linear_block16<4>(a, a.g[z], lds, rt, cg, tid, lane, wave, flag);
+        } else {
+            const int rt = b % f.row_tiles, z = b / f.row_tiles;
+            int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * stride + kHandoffWord);
+            linear_block16<1>(a, a.g[z], lds, rt, 0, tid, lane, wave, flag);
+        }
         return;
     }
     const int grp = b - f.nlin;
     int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)grp * stride + kHandoffWord);
-    latent_body<true>(f.ka, lds, grp, flag, 4 * f.la.ngroups);
+    latent_body<true>(f.ka, lds, grp, flag, f.ks * f.la.ngroups);
 }
 
 // Scalars of the step from the row tiles' partial sums, in a fixed order
@@ -1352,11 +1362,15 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     // Small training batches: encoder layer and per-sample chain in ONE launch
     // (k_fused).  Needs full 16-row groups and the whole grid resident at once to pay.
     const int row_tiles = cdiv(ka.st.n, kRows);
-    const int nlin = 4 * row_tiles * la.ngroups;
+    int ks = 4, nlin = 4 * row_tiles * la.ngroups;
+    if (nlin + row_tiles > fuse_blocks()) {   // too many 64-column tiles: 256-column ones
+        ks = 1;
+        nlin = row_tiles * la.ngroups;
+    }
     if (ka.lds.rows == kRows && ka.st.group_rows == 0 && nlin + row_tiles <= fuse_blocks() && !no_fuse()) {
         static thread_local int lds_opted_f = 0;
         const int kp = round_up(maxd < kEncKChunk ? maxd : kEncKChunk, 16);
-        const int lin_lds = (kRows + kRows * (kp + 4) + 4 * kRows * 68) * (int)sizeof(float);
+        const int lin_lds = (kRows + kRows * (kp + 4) + (ks == 4 ? 4 * kRows * 68 : kRows * 260)) * (int)sizeof(float);
         if (lin_lds > lds) lds = lin_lds;
         if (lds > 64 * 1024 && lds > lds_opted_f) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused),
@@ -1369,6 +1383,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         fa.la = la;
         fa.nlin = nlin;
         fa.row_tiles = row_tiles;
+        fa.ks = ks;
         {
             ProfScope ps(MOPOE_KERNEL_FUSED, s);
             hipLaunchKernelGGL(k_fused, dim3(nlin + row_tiles), dim3(kLatentThreads), (size_t)lds, s, fa);

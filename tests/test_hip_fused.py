@@ -26,7 +26,7 @@ def _train(steps, seed, n=256):
     return eng.params.clone(), eng.exp_avg_sq.clone()
 
 
-@pytest.mark.parametrize("n", [256, 100, 16])
+@pytest.mark.parametrize("n", [256, 100, 16, 1024])
 def test_fused_launch_is_bit_identical_to_three_launches(n, monkeypatch):
     monkeypatch.delenv("MOPOE_NO_FUSE", raising=False)
     fused = _train(3000, 5, n)
