@@ -13,7 +13,9 @@ MAX_SUBSETS = 31
 MAX_JOBS = 10
 HIDDEN = 256
 ROWS = 16
-ABI_VERSION = 4
+ABI_VERSION = 5
+MAX_RANKS = 8
+IPC_HANDLE_BYTES = 64
 
 SUB_POE, SUB_POE_PRIOR, SUB_SLICES = 0, 1, 2
 JOINT_MIXTURE, JOINT_MEAN, JOINT_EXPERT = 0, 1, 2
@@ -24,7 +26,8 @@ STAT_KLD_SUBSET = 2
 STAT_KLD_STYLE = 2 + MAX_SUBSETS
 STAT_NLL = STAT_KLD_STYLE + MAX_MODS
 NUM_STATS = STAT_NLL + MAX_JOBS
-KERNEL_NAMES = ("k_linear", "k_latent", "k_wgrad", "k_adam", "k_finalize", "k_fused")
+KERNEL_NAMES = ("k_linear", "k_latent", "k_wgrad", "k_adam", "k_finalize", "k_fused",
+                "k_xgmi")
 
 _i32 = C.c_int32
 _u8 = C.c_uint8
@@ -135,6 +138,14 @@ SYMBOLS = {
                                    C.POINTER(Buffers), C.POINTER(Adam), _ptr]),
     "mopoe_adam_step": (C.c_int, [C.POINTER(Model), _i32, C.POINTER(Buffers),
                                   C.POINTER(Adam), _f32, _i32, _ptr]),
+    "mopoe_comm_create": (C.c_int, [_i32, _i32, _i32, _i32, C.POINTER(_ptr), _ptr]),
+    "mopoe_comm_connect": (C.c_int, [_ptr, _ptr]),
+    "mopoe_comm_allreduce": (C.c_int, [_ptr, _ptr, _ptr]),
+    "mopoe_comm_allreduce_adam": (C.c_int, [_ptr, C.POINTER(Model), _i32,
+                                            C.POINTER(Buffers), C.POINTER(Adam), _i32,
+                                            _ptr]),
+    "mopoe_comm_status": (C.c_int, [_ptr, C.POINTER(_i32)]),
+    "mopoe_comm_destroy": (C.c_int, [_ptr]),
     "mopoe_linear": (C.c_int, [_ptr, _i32, _i32, _ptr, _ptr, _i32, _i32, _ptr,
                                _ptr]),
     "mopoe_poe": (C.c_int, [_ptr, _ptr, _i32, C.c_int64, _f32, _ptr, _ptr,

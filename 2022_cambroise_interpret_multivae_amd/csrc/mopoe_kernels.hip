@@ -185,6 +185,10 @@ DEV AdamCoef adam_coef_resolve(const AdamCoefRaw& r, const mopoe_adam& ad) {
 
 DEV void adam_update(const AdamCoef& c, float g, float p, float m, float v, float* po,
                      float* mo, float* vo) {
+    // every operation rounds by itself, like the separate tensor ops of torch's Adam --
+    // and the three kernels that inline this (k_wgrad, k_adam, k_xgmi) then agree bit
+    // for bit instead of each getting its own choice of fused multiply-adds
+#pragma clang fp contract(off)
     const float m1 = m + c.one_m_b1 * (g - m);           // exp_avg.lerp_(g, 1-b1)
     const float v1 = v * c.b2 + (c.one_m_b2 * g) * g;     // mul_(b2).addcmul_(g, g, 1-b2)
     const float denom = sqrtf(v1) / c.bc2_sqrt + c.eps;
@@ -1075,7 +1079,8 @@ __global__ __launch_bounds__(256) void k_adam(const mopoe_buffers buf, const Ada
     const int beg = s.begin[blockIdx.y], end = s.end[blockIdx.y];
     for (int i = beg + blockIdx.x * blockDim.x + threadIdx.x; i < end;
          i += gridDim.x * blockDim.x) {
-        const float g = buf.grads[i] * s.grad_scale;
+        // a multiply of its own (never contracted into the update), as in k_xgmi
+        const float g = __fmul_rn(buf.grads[i], s.grad_scale);
         adam_update(ac, g, buf.params[i], buf.exp_avg[i], buf.exp_avg_sq[i], buf.params + i,
                     buf.exp_avg + i, buf.exp_avg_sq + i);
     }
@@ -1445,7 +1450,37 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w) {
     if (adam) w.adam = *adam;
 }
 
+int build_adam_segs(const mopoe_model& mdl, int32_t present_mask, const mopoe_adam& adam,
+                    float grad_scale, int32_t step, AdamSegs& sg) {
+    memset(&sg, 0, sizeof(sg));
+    for (int m = 0; m < mdl.num_mods; ++m) {
+        if (!((present_mask >> m) & 1)) continue;
+        sg.begin[sg.nseg] = mdl.off_w1[m];
+        sg.end[sg.nseg++] = mdl.off_bh[m] + heads_dim(mdl, m);
+        sg.begin[sg.nseg] = mdl.off_wd[m];
+        sg.end[sg.nseg++] = mdl.learn_output_scale ? mdl.off_lvo[m] + mdl.input_dim[m]
+                                                   : mdl.off_bd[m] + mdl.input_dim[m];
+    }
+    if (sg.nseg == 0) return fail(MOPOE_ERR_ARG, "empty present_mask%s");
+    sg.grad_scale = grad_scale;
+    sg.adam = adam;
+    if (step > 0) {  // same arithmetic as adam_coef(), done once on the host
+        const double b1 = (double)adam.beta1, b2 = (double)adam.beta2;
+        sg.host_coef = 1;
+        sg.coef.b2 = adam.beta2;
+        sg.coef.one_m_b1 = (float)(1.0 - b1);
+        sg.coef.one_m_b2 = (float)(1.0 - b2);
+        sg.coef.step_size = (float)((double)adam.lr / (1.0 - pow(b1, (double)step)));
+        sg.coef.bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)step));
+        sg.coef.eps = adam.eps;
+        sg.coef.pad = 0.f;
+    }
+    return 0;
+}
+
 }  // namespace
+
+#include "mopoe_xgmi.inc"
 
 extern "C" {
 
@@ -1583,29 +1618,7 @@ int mopoe_adam_step(const mopoe_model* mdl, int32_t present_mask, const mopoe_bu
     if (!buf->params || !buf->grads || !buf->exp_avg || !buf->exp_avg_sq || !buf->counters)
         return fail(MOPOE_ERR_ARG, "null optimiser buffer%s");
     AdamSegs sg;
-    memset(&sg, 0, sizeof(sg));
-    for (int m = 0; m < mdl->num_mods; ++m) {
-        if (!((present_mask >> m) & 1)) continue;
-        sg.begin[sg.nseg] = mdl->off_w1[m];
-        sg.end[sg.nseg++] = mdl->off_bh[m] + heads_dim(*mdl, m);
-        sg.begin[sg.nseg] = mdl->off_wd[m];
-        sg.end[sg.nseg++] = mdl->learn_output_scale ? mdl->off_lvo[m] + mdl->input_dim[m]
-                                                    : mdl->off_bd[m] + mdl->input_dim[m];
-    }
-    if (sg.nseg == 0) return fail(MOPOE_ERR_ARG, "empty present_mask%s");
-    sg.grad_scale = grad_scale;
-    sg.adam = *adam;
-    if (step > 0) {  // same arithmetic as adam_coef(), done once on the host
-        const double b1 = (double)adam->beta1, b2 = (double)adam->beta2;
-        sg.host_coef = 1;
-        sg.coef.b2 = adam->beta2;
-        sg.coef.one_m_b1 = (float)(1.0 - b1);
-        sg.coef.one_m_b2 = (float)(1.0 - b2);
-        sg.coef.step_size = (float)((double)adam->lr / (1.0 - pow(b1, (double)step)));
-        sg.coef.bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)step));
-        sg.coef.eps = adam->eps;
-        sg.coef.pad = 0.f;
-    }
+    if (int rc = build_adam_segs(*mdl, present_mask, *adam, grad_scale, step, sg)) return rc;
     {
         ProfScope ps(MOPOE_KERNEL_ADAM, static_cast<hipStream_t>(stream));
         hipLaunchKernelGGL(k_adam, dim3(128, sg.nseg), dim3(256), 0,
@@ -1679,6 +1692,105 @@ int mopoe_mixture_select(const float* mus, const float* logvars, int32_t num_com
                        static_cast<hipStream_t>(stream), mus, logvars, num_comp, n, d, bounds,
                        out_mu, out_logvar);
     return check_launch("k_mix_select");
+}
+
+// ---- data-parallel gradient exchange over xGMI peer windows (mopoe_xgmi.inc) ----------
+int mopoe_comm_create(int32_t rank, int32_t world, int32_t num_floats, int32_t timeout_ms,
+                      mopoe_comm** out, void* handle_out) {
+    if (!out || !handle_out || world < 1 || world > MOPOE_MAX_RANKS || rank < 0 ||
+        rank >= world || num_floats < 4 || num_floats % 4 != 0)
+        return fail(MOPOE_ERR_ARG, "mopoe_comm_create: bad argument%s");
+    static_assert(sizeof(hipIpcMemHandle_t) == MOPOE_IPC_HANDLE_BYTES, "handle size");
+    mopoe_comm* c = new mopoe_comm();
+    memset(c, 0, sizeof(*c));
+    c->rank = rank;
+    c->world = world;
+    c->num_floats = num_floats;
+    c->p4 = num_floats / 4;
+    c->nchunks = cdiv(c->p4, kXgThreads);
+    if (c->nchunks > kXgMaxChunks) {
+        delete c;
+        return fail(MOPOE_ERR_ARG, "mopoe_comm_create: buffer too large%s");
+    }
+    c->p4pad = (size_t)c->nchunks * kXgThreads;
+    const size_t inbox = 2 * (size_t)world * c->p4pad * 16;
+    c->flags_off = inbox;
+    c->status_off = inbox + (((size_t)world * c->nchunks * 4 + 255) / 256) * 256;
+    c->bytes = c->status_off + 256;
+    if (timeout_ms < 1) timeout_ms = 2000;
+    if (timeout_ms > 20000) timeout_ms = 20000;
+    c->timeout_ticks = (uint32_t)timeout_ms * 100000u;   // s_memrealtime: 100 MHz
+    hipError_t e = hipExtMallocWithFlags(&c->window, c->bytes, hipDeviceMallocUncached);
+    if (e == hipSuccess) e = hipMemset(c->window, 0, c->bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    hipIpcMemHandle_t h;
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, c->window);
+    if (e != hipSuccess) {
+        if (c->window) (void)hipFree(c->window);
+        delete c;
+        return fail(MOPOE_ERR_HIP, "mopoe_comm_create: %s", hipGetErrorString(e));
+    }
+    memcpy(handle_out, &h, sizeof(h));
+    c->mapped[rank] = c->window;
+    *out = c;
+    return 0;
+}
+
+int mopoe_comm_connect(mopoe_comm* c, const void* handles) {
+    if (!c || !handles) return fail(MOPOE_ERR_ARG, "mopoe_comm_connect: null argument%s");
+    if (c->connected) return fail(MOPOE_ERR_ARG, "mopoe_comm_connect: already connected%s");
+    for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, static_cast<const char*>(handles) + (size_t)r * sizeof(h), sizeof(h));
+        hipError_t e = hipIpcOpenMemHandle(&c->mapped[r], h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            for (int q = 0; q < r; ++q)
+                if (q != c->rank && c->mapped[q]) {
+                    (void)hipIpcCloseMemHandle(c->mapped[q]);
+                    c->mapped[q] = nullptr;
+                }
+            return fail(MOPOE_ERR_HIP, "hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+        }
+    }
+    c->connected = true;
+    return 0;
+}
+
+int mopoe_comm_allreduce(mopoe_comm* c, float* data, void* stream) {
+    if (!c || !data) return fail(MOPOE_ERR_ARG, "mopoe_comm_allreduce: null argument%s");
+    return comm_launch(c, data, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int mopoe_comm_allreduce_adam(mopoe_comm* c, const mopoe_model* mdl, int32_t present_mask,
+                              const mopoe_buffers* buf, const mopoe_adam* adam, int32_t step,
+                              void* stream) {
+    if (!c || !mdl || !buf || !adam) return fail(MOPOE_ERR_ARG, "null descriptor%s");
+    if (!buf->params || !buf->grads || !buf->exp_avg || !buf->exp_avg_sq || !buf->counters)
+        return fail(MOPOE_ERR_ARG, "null optimiser buffer%s");
+    if (mdl->num_floats != c->num_floats)
+        return fail(MOPOE_ERR_ARG, "communicator was created for another buffer length%s");
+    AdamSegs sg;
+    if (int rc = build_adam_segs(*mdl, present_mask, *adam, 1.0f / (float)c->world, step, sg))
+        return rc;
+    return comm_launch(c, buf->grads, buf, &sg, static_cast<hipStream_t>(stream));
+}
+
+int mopoe_comm_status(mopoe_comm* c, int32_t* timeouts) {
+    if (!c || !timeouts) return fail(MOPOE_ERR_ARG, "mopoe_comm_status: null argument%s");
+    hipError_t e = hipMemcpy(timeouts, static_cast<char*>(c->window) + c->status_off, 4,
+                             hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(MOPOE_ERR_HIP, "mopoe_comm_status: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int mopoe_comm_destroy(mopoe_comm* c) {
+    if (!c) return 0;
+    for (int r = 0; r < c->world; ++r)
+        if (r != c->rank && c->mapped[r]) (void)hipIpcCloseMemHandle(c->mapped[r]);
+    if (c->window) (void)hipFree(c->window);
+    delete c;
+    return 0;
 }
 
 }  // extern "C"

@@ -25,10 +25,16 @@ def allreduce_mean_(flat_grads):
 
 
 class DataParallelStep:
-    """engine.train_step + gradient all-reduce + engine.adam_step."""
+    """engine.train_step + gradient all-reduce + engine.adam_step.
 
-    def __init__(self, engine):
+    `comm`: an XgmiComm (comm.py) -- the exchange and the Adam update are then
+    ONE launch over the node's xGMI peer windows instead of the library
+    all-reduce followed by the Adam kernel; the sum is taken in rank order, so
+    replicas stay bit-identical."""
+
+    def __init__(self, engine, comm=None):
         self.engine = engine
+        self.comm = comm
         broadcast_parameters(engine.params)
         broadcast_parameters(engine.exp_avg)
         broadcast_parameters(engine.exp_avg_sq)
@@ -39,6 +45,9 @@ class DataParallelStep:
         if world == 1:
             return eng.train_step(batch, eps=eps, apply_adam=True)
         out = eng.train_step(batch, eps=eps, apply_adam=False)
+        if self.comm is not None:
+            self.comm.allreduce_adam(eng)
+            return out
         scale = allreduce_mean_(eng.grads)
         eng.adam_step(grad_scale=scale)
         return out

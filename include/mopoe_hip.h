@@ -28,11 +28,13 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 4
+#define MOPOE_ABI_VERSION 5
 #define MOPOE_MAX_MODS 5      /* modalities                                   */
 #define MOPOE_MAX_SUBSETS 31  /* 2^MAX_MODS - 1 non-empty subsets             */
 #define MOPOE_MAX_JOBS 10     /* decoder passes: 1 joint + 1 unimodal per mod */
 #define MOPOE_HIDDEN 256      /* networks/networks.py:14,50 (hard-coded)      */
+#define MOPOE_MAX_RANKS 8     /* GPUs of one node (xGMI full mesh)            */
+#define MOPOE_IPC_HANDLE_BYTES 64
 #define MOPOE_ROWS 16         /* batch rows per MFMA tile; a row group has <= 16 */
 
 #define MOPOE_ERR_ARG (-1)
@@ -216,7 +218,8 @@ typedef struct mopoe_adam {
 #define MOPOE_KERNEL_ADAM 3
 #define MOPOE_KERNEL_FINALIZE 4
 #define MOPOE_KERNEL_FUSED 5   /* encoder layer + per-sample chain in one launch */
-#define MOPOE_NUM_KERNELS 6
+#define MOPOE_KERNEL_XGMI 6    /* gradient exchange over xGMI + Adam in one launch */
+#define MOPOE_NUM_KERNELS 7
 int mopoe_profile_enable(int enable);
 int mopoe_profile_read(int32_t* count, float* total_ms);
 
@@ -266,6 +269,43 @@ int mopoe_train_step(const mopoe_model* model, const mopoe_step* step,
 int mopoe_adam_step(const mopoe_model* model, int32_t present_mask,
                     const mopoe_buffers* buf, const mopoe_adam* adam,
                     float grad_scale, int32_t step, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Data-parallel replicas on one node (the reference has no
+ * distributed code, so there is nothing to cite beyond the optimizer step the
+ * exchange feeds, experiment.py:256-279).  A communicator owns one device
+ * "window" per rank (uncached device memory: two inboxes of `world` gradient
+ * buffers + arrival flags), exported to the other ranks' processes with
+ * hipIpcGetMemHandle; this is the one object of the library that allocates.
+ *
+ *   mopoe_comm_create   allocates the window and returns its 64-byte IPC handle;
+ *                       the caller exchanges the handles out of band (e.g.
+ *                       torch.distributed.all_gather_object) ...
+ *   mopoe_comm_connect  ... and passes all `world` of them (rank order).
+ *   mopoe_comm_allreduce_adam
+ *                       replaces `all_reduce(grads); mopoe_adam_step(1/world)`:
+ *                       ONE launch that pushes buf->grads to every peer over its
+ *                       xGMI link, waits (bounded by timeout_ms) for the peers'
+ *                       pushes, sums the copies in rank order (bit-identical on all
+ *                       ranks), leaves the sum in buf->grads and applies Adam with
+ *                       the mean.  All ranks must call it the same number of times.
+ *   mopoe_comm_allreduce
+ *                       the same exchange without the update: data (num_floats) is
+ *                       replaced by the rank-ordered sum.
+ *   mopoe_comm_status   waits for nothing: copies the count of timed-out waits
+ *                       (0 = every exchange so far was complete).
+ *   mopoe_comm_destroy  unmaps and frees; call after a barrier over the ranks.
+ * ------------------------------------------------------------------------- */
+typedef struct mopoe_comm mopoe_comm;
+int mopoe_comm_create(int32_t rank, int32_t world, int32_t num_floats, int32_t timeout_ms,
+                      mopoe_comm** comm, void* handle_out);
+int mopoe_comm_connect(mopoe_comm* comm, const void* handles);
+int mopoe_comm_allreduce(mopoe_comm* comm, float* data, void* stream);
+int mopoe_comm_allreduce_adam(mopoe_comm* comm, const mopoe_model* model,
+                              int32_t present_mask, const mopoe_buffers* buf,
+                              const mopoe_adam* adam, int32_t step, void* stream);
+int mopoe_comm_status(mopoe_comm* comm, int32_t* timeouts);
+int mopoe_comm_destroy(mopoe_comm* comm);
 
 /* Free functions of section 8b, float32 device tensors. */
 

@@ -1,0 +1,48 @@
+"""The xGMI gradient exchange (csrc/mopoe_xgmi.inc, comm.py) between real
+processes: W ranks, each with its own window, all on the box's one GPU (peer
+windows between processes of the same device use the same IPC path as between
+the GPUs of a node).  Checked bit for bit against the rank-ordered sum and
+against `all-reduce + mopoe_adam_step`."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_exchange_and_fused_adam_between_processes(world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   # W processes share this box's one GPU: the fused launch assumes its
+                   # whole grid is resident, which other processes' grids on the same
+                   # CUs break -- the ranks run the three-launch form here (same bits,
+                   # tests/test_hip_fused.py); on the node every rank has its own GPU
+                   MOPOE_NO_FUSE="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "xgmi_worker.py")],
+                                      env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=240)
+            outs.append(out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    bad = ["rank %d (rc %s):\n%s" % (r, p.returncode, out[-1500:])
+           for r, (p, out) in enumerate(zip(procs, outs)) if p.returncode != 0]
+    assert not bad, "\n".join(bad)
+    if os.environ.get("XGMI_TIME"):
+        print("\n".join(l for out in outs for l in out.splitlines() if "us per" in l))
