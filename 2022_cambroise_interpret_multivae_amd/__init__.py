@@ -5,3 +5,4 @@ the `mopoe_amd` alias module at the repository root."""
 from . import _lib  # noqa: F401  (fails loudly if libmopoe_hip.so is missing)
 from .plan import ModelSpec, StepPlan  # noqa: F401
 from .engine import MoPoEEngine  # noqa: F401
+from . import comm  # noqa: F401

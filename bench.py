@@ -14,7 +14,12 @@ reference logs every step, run_epochs.py:184).
 
 For N > 1 the driver launches one rank per GPU with torch.distributed.run;
 ranks are data-parallel replicas (weak scaling: 256 samples per GPU per
-step) and all-reduce the flat gradient buffer once per step.
+step) that exchange the flat gradient buffer once per step: one launch per
+rank over xGMI peer windows (push to every peer, rank-ordered sum, Adam --
+csrc/mopoe_xgmi.inc) after a start-up check of that exchange against the
+gathered inputs on this very node; if the windows cannot be set up or the
+check fails, the step is RCCL all_reduce + the Adam kernel, and `config.exchange`
+says which one ran (MOPOE_EXCHANGE=rccl|xgmi pins it).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the largest
 share of device time, its duration measured with HIP events on the launch
@@ -48,7 +53,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
-def kernel_models(spec, n, fused_adam):
+def kernel_models(spec, n, fused_adam, world=1):
     """Algorithmic flops / HBM bytes per launch of each kernel at batch n
     (DESIGN.md section 5 derives these from SURVEY.md section 8d)."""
     M = spec.num_mods
@@ -88,6 +93,8 @@ def kernel_models(spec, n, fused_adam):
     out["k_fused"] = dict(flops=out["k_linear"]["flops"] + out["k_latent"]["flops"],
                           bytes=out["k_linear"]["bytes"] + out["k_latent"]["bytes"])
     out["k_adam"] = dict(flops=0.0, bytes=f * 7 * P)
+    # push to W-1 peers, read W-1 inboxes, sum written back, Adam read-modify-write
+    out["k_xgmi"] = dict(flops=0.0, bytes=f * P * (8 + 2 * (world - 1)))
     out["k_finalize"] = dict(flops=0.0, bytes=0.0)
     return out
 
@@ -155,6 +162,42 @@ def cpu_baseline(seconds=10.0):
             "other_thread_counts": {str(k): round(v[0], 1) for k, v in runs.items()}}
 
 
+def open_xgmi(num_floats, device, rank, world, dist):
+    """Set up the peer windows and CHECK the exchange on this node before it is
+    trusted with the timed region: three exchanges (both inbox parities) of
+    rank-dependent data must equal, bit for bit, the rank-ordered sum of the
+    inputs gathered over the process group.  Returns (comm, "") or (None, why)."""
+    XgmiComm = mm.comm.XgmiComm
+    try:
+        comm = XgmiComm(num_floats, timeout_ms=2000)
+    except mm._lib.MopoeError as e:
+        return None, "peer windows unavailable: %s" % e
+    ok = 1.0
+    try:
+        g = torch.Generator().manual_seed(4321 + rank)
+        for _ in range(3):
+            mine = torch.randn(num_floats, generator=g).to(device)
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            want = parts[0].clone()
+            for q in parts[1:]:
+                want += q
+            got = comm.allreduce_(mine.clone())
+            torch.cuda.synchronize()
+            if not torch.equal(got, want):
+                ok = 0.0
+        if comm.timeouts():
+            ok = 0.0
+    except mm._lib.MopoeError:
+        ok = 0.0
+    flag = torch.tensor([ok], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if flag.item() != 1.0:
+        comm.close()
+        return None, "start-up check of the xGMI exchange failed on this node"
+    return comm, ""
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,12 +236,26 @@ def main():
                 for _ in range(8)]
     fused = dist is None
 
+    # ---- the gradient exchange of the N-rank step
+    comm, exchange, why = None, "none", ""
+    if dist is not None:
+        exchange = os.environ.get("MOPOE_EXCHANGE", "auto")
+        if exchange not in ("auto", "xgmi", "rccl"):
+            sys.exit("MOPOE_EXCHANGE must be auto, xgmi or rccl")
+        if exchange != "rccl":
+            comm, why = open_xgmi(spec.num_floats, device, rank, world, dist)
+            if comm is None and exchange == "xgmi":
+                sys.exit("MOPOE_EXCHANGE=xgmi but: " + why)
+            exchange = "xgmi" if comm is not None else "rccl"
+
     def step(i):
         # the step's scalar log lands in a ring of pinned host buffers, written
         # by the kernel itself (no copy on the stream)
         plan, ws = eng.train_step(pool[(i * world + rank) % POOL], apply_adam=fused,
                                   stats_host=None if args.no_log_copy else log_ring[i % 8])
-        if not fused:
+        if comm is not None:
+            comm.allreduce_adam(eng)                # one launch: push, sum, Adam
+        elif not fused:
             dist.all_reduce(eng.grads)              # RCCL, one flat buffer
             eng.adam_step(grad_scale=1.0 / world)
         return ws
@@ -209,14 +266,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ws = step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed():
+        for i in range(args.warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            ws = step(args.warmup + i)
+        barrier()
+        return time.perf_counter() - t0, ws
+
+    dt, ws = timed()
+    if comm is not None:
+        # the exchange must have been complete in every step, and the replicas identical
+        bad = torch.tensor([comm.timeouts(), 0], device=device, dtype=torch.float64)
+        mine = eng.params.double().sum()
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        bad[1] = float(lo.item() != hi.item())
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if bad[0].item() or bad[1].item():
+            if os.environ.get("MOPOE_EXCHANGE") == "xgmi":
+                sys.exit("xGMI exchange: %d timed-out waits, replicas differ: %s"
+                         % (int(bad[0].item()), bool(bad[1].item())))
+            why = "timed region over xGMI invalid (%d timeouts, replicas differ: %s); " \
+                  "re-run over RCCL" % (int(bad[0].item()), bool(bad[1].item()))
+            comm.close()
+            comm, exchange = None, "rccl"
+            eng.reset_parameters(torch.Generator().manual_seed(0))
+            eng.exp_avg.zero_()
+            eng.exp_avg_sq.zero_()
+            dt, ws = timed()
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -244,6 +325,12 @@ def main():
                                "style 3,20, batch 256 per GPU, Adam lr 0.002",
                    "global_batch": BATCH * world,
                    "parallelism": "dp%d" % world if dist is not None else "single",
+                   "exchange": {"none": "none (single GPU: Adam fused into the "
+                                        "weight-gradient launch)",
+                                "xgmi": "one launch per rank over xGMI peer windows: push "
+                                        "to every peer, rank-ordered sum, Adam",
+                                "rccl": "RCCL all_reduce of the flat buffer + Adam kernel"
+                                }[exchange] + (" [%s]" % why if why else ""),
                    "host_log_every_step": not args.no_log_copy,
                    "final_loss": round(loss, 3)},
     }
@@ -257,7 +344,7 @@ def main():
         torch.cuda.synchronize()
         prof = mm._lib.profile_read()
         mm._lib.profile_enable(False)
-        models = kernel_models(spec, BATCH, fused)
+        models = kernel_models(spec, BATCH, fused, world)
         total_ms = sum(ms for _, ms in prof.values()) or 1.0
         name = max(prof, key=lambda k: prof[k][1])
         cnt, ms = prof[name]
@@ -304,6 +391,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
