@@ -144,6 +144,8 @@ SYMBOLS = {
     "mopoe_comm_allreduce_adam": (C.c_int, [_ptr, C.POINTER(Model), _i32,
                                             C.POINTER(Buffers), C.POINTER(Adam), _i32,
                                             _ptr]),
+    "mopoe_comm_train_step": (C.c_int, [_ptr, C.POINTER(Model), C.POINTER(Step),
+                                        C.POINTER(Buffers), C.POINTER(Adam), _ptr]),
     "mopoe_comm_status": (C.c_int, [_ptr, C.POINTER(_i32)]),
     "mopoe_comm_destroy": (C.c_int, [_ptr]),
     "mopoe_linear": (C.c_int, [_ptr, _i32, _i32, _ptr, _ptr, _i32, _i32, _ptr,

@@ -584,6 +584,62 @@ DEV void stg4_wt(rsrc_t r, uint32_t byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 16);
 }
 
+// System-scope accesses (sc0 sc1): write-through / read-through past both cache levels,
+// for memory another GPU writes or reads while the kernel runs (the xGMI peer windows).
+DEV f32x4 ld16_sys(rsrc_t r, uint32_t off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 17));
+}
+DEV float ld4_sys(rsrc_t r, uint32_t off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 17));
+}
+DEV void st16_sys(rsrc_t r, uint32_t off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 17);
+}
+DEV void st4_sys(rsrc_t r, uint32_t off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, off, 0, 17);
+}
+
+// The exchange descriptor a kernel needs to reach the peers' windows (mopoe_xgmi.inc).
+struct XgPeers {
+    int32_t rank, world;
+    uint32_t seq, parity, timeout_ticks;
+    int32_t flag_stride;                 // flag words per source rank
+    float inv_world;
+    int32_t pad;
+    size_t p4pad;                        // float4 per (parity, source) inbox
+    size_t flags_off, status_off;        // byte offsets inside a window
+    void* window[MOPOE_MAX_RANKS];       // base of every rank's window as mapped HERE
+};
+
+// Publishes `seq` in flags[me][slot] of every peer, then waits (bounded) until every
+// peer's flags[peer][slot] HERE has reached it.  Called by the threads tid < world of a
+// workgroup (or wave) whose pushes have drained (s_waitcnt vmcnt(0) + barrier).
+DEV void xg_signal_and_wait(const XgPeers& x, int tid, int slot) {
+    if (tid >= x.world || tid == x.rank) return;
+    uint32_t* out = reinterpret_cast<uint32_t*>(static_cast<char*>(x.window[tid]) + x.flags_off) +
+                    (size_t)x.rank * x.flag_stride + slot;
+    __hip_atomic_store(out, x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t* in = reinterpret_cast<const uint32_t*>(
+                             static_cast<const char*>(x.window[x.rank]) + x.flags_off) +
+                         (size_t)tid * x.flag_stride + slot;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const uint32_t got = __hip_atomic_load(in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t)(got - x.seq) >= 0) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > x.timeout_ticks) {
+            int32_t* st = reinterpret_cast<int32_t*>(static_cast<char*>(x.window[x.rank]) +
+                                                     x.status_off);
+            __hip_atomic_fetch_add(st, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+// byte offset of inbox[parity][src] inside a window
+DEV size_t xg_inbox(const XgPeers& x, int src) {
+    return ((size_t)x.parity * x.world + src) * x.p4pad * 16;
+}
+
 // B fragment of Y = A * W^T: W is (ncols, K) row-major with row stride ldw;
 // r covers ncols * ldw floats, so col >= ncols is out of range by itself.
 // VEC: K % 4 == 0 (then a 4-wide read never crosses a row end).

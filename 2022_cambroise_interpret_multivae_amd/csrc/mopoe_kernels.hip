@@ -772,6 +772,7 @@ struct WArgs {
     WJob jobs[3 * MOPOE_MAX_MODS];
     int32_t lvo_block_begin[MOPOE_MAX_MODS + 1];
     mopoe_adam adam;
+    XgPeers xg;            // k_wgrad<.., true>: the exchange between backward and update
 };
 
 // One wave's share of a 32x32 block of G^T X: batch rows [rbeg, rend) in rounds
@@ -835,7 +836,13 @@ constexpr int kWgLd = 36;  // leading dim of a 32x32 partial block in LDS
 // kWgWaves waves split the batch rows of a block: 8 for large batches (twice as fast at
 // N >= 1024), 4 for small ones (at N = 256 the longer reduction and the larger
 // workgroups cost more than the shorter MFMA chains save).
-template <int kWgWaves>
+//
+// XG (data-parallel replicas, mopoe_comm_train_step): between the block's gradient and
+// its Adam update sits the exchange of mopoe_xgmi.inc, per block: the 32x32 block (and
+// its bias column) is pushed into every peer's inbox at its place in the flat buffer,
+// the block's flag is raised at every peer, the peers' copies are awaited and added in
+// rank order.  The N-rank step then has the same two launches as the one-rank step.
+template <int kWgWaves, bool XG>
 __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
                                                          const WArgs w_by_value) {
     __shared__ __attribute__((aligned(16))) float blk[kWgWaves][32 * kWgLd];
@@ -937,8 +944,8 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         __syncthreads();
         // fixed-order sum of the four partials, 4 consecutive columns per thread
         asm volatile("" ::"s"(karg_sink));  // (keeps the prefetch loads alive)
-        if (!epi) return;
-        const int li = tid >> 3, lj = 4 * (tid & 7);
+        if (!XG && !epi) return;   // (XG: every wave stays for the exchange's barriers)
+        const int li = (tid >> 3) & 31, lj = 4 * (tid & 7);
         f32x4 g = *reinterpret_cast<const f32x4*>(&blk[0][li * kWgLd + lj]);
 #pragma unroll
         for (int k = 1; k < kWgWaves; ++k)  // fixed order
@@ -946,13 +953,71 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         GSTAMP(buf.stats, 64 + 43, stamp_blk);
         AdamCoef ac;
         if (fuse) ac = adam_coef_resolve(acr, w.adam);
+        const int eb = xcols - ej;   // has_b: the bias column inside this thread's four
+        float gb = eb == 0 ? g[0] : eb == 1 ? g[1] : eb == 2 ? g[2] : g[3];
+        float gscale = 1.f;
+        if constexpr (XG) {
+            const XgPeers& x = w.xg;
+            const int W = x.world, me = x.rank;
+            gscale = x.inv_world;
+            // where this thread's values sit in the flat buffer: one 16-byte access for
+            // a full group of four, single words at a row end, the bias word
+            const uint32_t o16 = guard((uint32_t)widx * 4u, nvalid >= 4);
+            uint32_t o1[3];
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                o1[e] = guard((uint32_t)(widx + e) * 4u, (nvalid < 4) & (e < nvalid));
+            const uint32_t ob = guard((uint32_t)bidx * 4u, has_b);
+#pragma unroll
+            for (int r = 0; r < MOPOE_MAX_RANKS; ++r) {
+                if (r >= W || r == me) continue;
+                const rsrc_t rr = make_rsrc(static_cast<char*>(x.window[r]) + xg_inbox(x, me),
+                                            pbytes);
+                st16_sys(rr, o16, g);
+#pragma unroll
+                for (int e = 0; e < 3; ++e) st4_sys(rr, o1[e], g[e]);
+                st4_sys(rr, ob, gb);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // pushes have landed
+            __syncthreads();
+            xg_signal_and_wait(x, tid, b);
+            __syncthreads();
+            f32x4 in[MOPOE_MAX_RANKS];
+            float inb[MOPOE_MAX_RANKS];
+#pragma unroll
+            for (int r = 0; r < MOPOE_MAX_RANKS; ++r) {
+                in[r] = z4;
+                inb[r] = 0.f;
+                if (r >= W || r == me) continue;
+                const rsrc_t rr = make_rsrc(static_cast<const char*>(x.window[me]) +
+                                                xg_inbox(x, r), pbytes);
+                const f32x4 v16 = ld16_sys(rr, o16);
+                f32x4 v1 = z4;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) v1[e] = ld4_sys(rr, o1[e]);
+                in[r] = nvalid >= 4 ? v16 : v1;
+                inb[r] = ld4_sys(rr, ob);
+            }
+            f32x4 s4 = me == 0 ? g : in[0];
+            float sb = me == 0 ? gb : inb[0];
+#pragma unroll
+            for (int r = 1; r < MOPOE_MAX_RANKS; ++r) {   // rank order, as k_xgmi
+                if (r >= W) continue;
+                s4 += r == me ? g : in[r];
+                sb += r == me ? gb : inb[r];
+            }
+            g = s4;
+            gb = sb;
+            if (!epi) return;
+        }
         if (nvalid > 0) {
             f32x4 np = pp, nm = pm, nv = pv;
             if (fuse) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float po, mo, vo;
-                    adam_update(ac, g[e], pp[e], pm[e], pv[e], &po, &mo, &vo);
+                    adam_update(ac, XG ? __fmul_rn(g[e], gscale) : g[e], pp[e], pm[e], pv[e],
+                                &po, &mo, &vo);
                     np[e] = po;
                     nm[e] = mo;
                     nv[e] = vo;
@@ -978,12 +1043,10 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
             }
         }
         if (has_b) {
-            const int e = xcols - ej;
-            const float gb = e == 0 ? g[0] : e == 1 ? g[1] : e == 2 ? g[2] : g[3];
             buf.grads[bidx] = gb;
             if (fuse)
-                adam_update(ac, gb, bp, bm, bv, buf.params + bidx, buf.exp_avg + bidx,
-                            buf.exp_avg_sq + bidx);
+                adam_update(ac, XG ? __fmul_rn(gb, gscale) : gb, bp, bm, bv, buf.params + bidx,
+                            buf.exp_avg + bidx, buf.exp_avg_sq + bidx);
         }
         GSTAMP(buf.stats, 64 + 44, stamp_blk);
         return;
@@ -1025,19 +1088,56 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         }
         blk[0][wave * 64 + lane] = g;
         __syncthreads();
-        if (on && wave == 0) {
+        if (wave == 0) {
             g = 0.f;
 #pragma unroll
             for (int k = 0; k < kWgWaves; ++k) g += blk[0][k * 64 + lane];  // fixed order
             const int idx = a.mdl.off_lvo[m] + col;
-            if (a.mdl.learn_output_scale) {
-                buf.grads[idx] = g;
-                if (fuse)
-                    adam_update(ac, g, buf.params[idx], buf.exp_avg[idx],
-                                buf.exp_avg_sq[idx], buf.params + idx, buf.exp_avg + idx,
-                                buf.exp_avg_sq + idx);
-            } else {
-                buf.grads[idx] = 0.f;
+            float gscale = 1.f;
+            if constexpr (XG) {
+                if (a.mdl.learn_output_scale) {   // this wave alone exchanges its 64 columns
+                    const XgPeers& x = w.xg;
+                    const int W = x.world, me = x.rank;
+                    gscale = x.inv_world;
+                    const size_t pbytes = (size_t)a.mdl.num_floats * sizeof(float);
+                    const uint32_t o = guard((uint32_t)idx * 4u, on);
+#pragma unroll
+                    for (int r = 0; r < MOPOE_MAX_RANKS; ++r) {
+                        if (r >= W || r == me) continue;
+                        const rsrc_t rr = make_rsrc(static_cast<char*>(x.window[r]) +
+                                                        xg_inbox(x, me), pbytes);
+                        st4_sys(rr, o, g);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    xg_signal_and_wait(x, lane, b);
+                    float in[MOPOE_MAX_RANKS];
+#pragma unroll
+                    for (int r = 0; r < MOPOE_MAX_RANKS; ++r) {
+                        in[r] = 0.f;
+                        if (r >= W || r == me) continue;
+                        const rsrc_t rr = make_rsrc(static_cast<const char*>(x.window[me]) +
+                                                        xg_inbox(x, r), pbytes);
+                        in[r] = ld4_sys(rr, o);
+                    }
+                    float s1 = me == 0 ? g : in[0];
+#pragma unroll
+                    for (int r = 1; r < MOPOE_MAX_RANKS; ++r) {
+                        if (r >= W) continue;
+                        s1 += r == me ? g : in[r];
+                    }
+                    g = s1;
+                }
+            }
+            if (on) {
+                if (a.mdl.learn_output_scale) {
+                    buf.grads[idx] = g;
+                    if (fuse)
+                        adam_update(ac, XG ? __fmul_rn(g, gscale) : g, buf.params[idx],
+                                    buf.exp_avg[idx], buf.exp_avg_sq[idx], buf.params + idx,
+                                    buf.exp_avg + idx, buf.exp_avg_sq + idx);
+                } else {
+                    buf.grads[idx] = 0.f;
+                }
             }
         }
         GSTAMP(buf.stats, 64 + 63, lb == w.lvo_blocks - 1 && tid == 0);
@@ -1411,7 +1511,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     return check_launch("k_latent");
 }
 
-void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w) {
+void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w, const XgPeers* xg = nullptr) {
     const mopoe_model& mdl = ka.mdl;
     const mopoe_step& st = ka.st;
     memset(&w, 0, sizeof(w));
@@ -1448,6 +1548,7 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w) {
     w.lvo_blocks = lb;
     w.fuse_adam = adam != nullptr;
     if (adam) w.adam = *adam;
+    if (xg) w.xg = *xg;
 }
 
 int build_adam_segs(const mopoe_model& mdl, int32_t present_mask, const mopoe_adam& adam,
@@ -1476,6 +1577,50 @@ int build_adam_segs(const mopoe_model& mdl, int32_t present_mask, const mopoe_ad
         sg.coef.pad = 0.f;
     }
     return 0;
+}
+
+void comm_next(mopoe_comm* c, XgPeers& x);
+int comm_check(const mopoe_comm* c, const mopoe_model* mdl);
+
+int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* buf,
+                    const mopoe_adam* adam, mopoe_comm* comm, void* stream) {
+    if (int rc = validate(mdl, st, buf, true)) return rc;
+    if (adam && (!buf->exp_avg || !buf->exp_avg_sq))
+        return fail(MOPOE_ERR_ARG, "null Adam state%s");
+    if (comm) {
+        if (!adam) return fail(MOPOE_ERR_ARG, "the exchanging step applies Adam: adam is NULL%s");
+        if (int rc = comm_check(comm, mdl)) return rc;
+    }
+    KArgs ka;
+    ka.mdl = *mdl;
+    ka.st = *st;
+    ka.buf = *buf;
+    ka.st.backward = 1;
+    ka.st.sample = 1;
+    latent_lds_layout(ka.mdl, ka.st, kLatentWaves, ka.lds);
+    latent_bind(ka.lds, ka.buf);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = launch_forward_part(ka, adam, s)) return rc;
+    WArgs w;
+    XgPeers xg;
+    if (comm) comm_next(comm, xg);
+    build_wargs(ka, adam, w, comm ? &xg : nullptr);
+    const dim3 grid(w.total_tiles + w.lvo_blocks + 1);
+    {
+        ProfScope ps(MOPOE_KERNEL_WGRAD, s);
+        if (ka.st.n > 512) {
+            if (comm)
+                hipLaunchKernelGGL((k_wgrad<8, true>), grid, dim3(512), 0, s, ka, w);
+            else
+                hipLaunchKernelGGL((k_wgrad<8, false>), grid, dim3(512), 0, s, ka, w);
+        } else {
+            if (comm)
+                hipLaunchKernelGGL((k_wgrad<4, true>), grid, dim3(256), 0, s, ka, w);
+            else
+                hipLaunchKernelGGL((k_wgrad<4, false>), grid, dim3(256), 0, s, ka, w);
+        }
+    }
+    return check_launch("k_wgrad");
 }
 
 }  // namespace
@@ -1585,31 +1730,7 @@ int mopoe_forward(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buff
 
 int mopoe_train_step(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* buf,
                      const mopoe_adam* adam, void* stream) {
-    if (int rc = validate(mdl, st, buf, true)) return rc;
-    if (adam && (!buf->exp_avg || !buf->exp_avg_sq))
-        return fail(MOPOE_ERR_ARG, "null Adam state%s");
-    KArgs ka;
-    ka.mdl = *mdl;
-    ka.st = *st;
-    ka.buf = *buf;
-    ka.st.backward = 1;
-    ka.st.sample = 1;
-    latent_lds_layout(ka.mdl, ka.st, kLatentWaves, ka.lds);
-    latent_bind(ka.lds, ka.buf);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (int rc = launch_forward_part(ka, adam, s)) return rc;
-    WArgs w;
-    build_wargs(ka, adam, w);
-    {
-        ProfScope ps(MOPOE_KERNEL_WGRAD, s);
-        if (ka.st.n > 512)
-            hipLaunchKernelGGL(k_wgrad<8>, dim3(w.total_tiles + w.lvo_blocks + 1), dim3(512), 0, s,
-                               ka, w);
-        else
-            hipLaunchKernelGGL(k_wgrad<4>, dim3(w.total_tiles + w.lvo_blocks + 1), dim3(256), 0, s, ka,
-                           w);
-    }
-    return check_launch("k_wgrad");
+    return train_step_impl(mdl, st, buf, adam, nullptr, stream);
 }
 
 int mopoe_adam_step(const mopoe_model* mdl, int32_t present_mask, const mopoe_buffers* buf,
@@ -1715,7 +1836,11 @@ int mopoe_comm_create(int32_t rank, int32_t world, int32_t num_floats, int32_t t
     c->p4pad = (size_t)c->nchunks * kXgThreads;
     const size_t inbox = 2 * (size_t)world * c->p4pad * 16;
     c->flags_off = inbox;
-    c->status_off = inbox + (((size_t)world * c->nchunks * 4 + 255) / 256) * 256;
+    // one flag word per source rank and per exchanging workgroup: k_xgmi has nchunks of
+    // them, the weight-gradient launch at most one per 64 parameters (a 32-row tile of
+    // a one-column weight plus its bias)
+    c->flag_stride = c->nchunks > num_floats / 64 + 64 ? c->nchunks : num_floats / 64 + 64;
+    c->status_off = inbox + (((size_t)world * c->flag_stride * 4 + 255) / 256) * 256;
     c->bytes = c->status_off + 256;
     if (timeout_ms < 1) timeout_ms = 2000;
     if (timeout_ms > 20000) timeout_ms = 20000;
@@ -1774,6 +1899,12 @@ int mopoe_comm_allreduce_adam(mopoe_comm* c, const mopoe_model* mdl, int32_t pre
     if (int rc = build_adam_segs(*mdl, present_mask, *adam, 1.0f / (float)c->world, step, sg))
         return rc;
     return comm_launch(c, buf->grads, buf, &sg, static_cast<hipStream_t>(stream));
+}
+
+int mopoe_comm_train_step(mopoe_comm* c, const mopoe_model* mdl, const mopoe_step* st,
+                          const mopoe_buffers* buf, const mopoe_adam* adam, void* stream) {
+    if (!c) return fail(MOPOE_ERR_ARG, "mopoe_comm_train_step: null communicator%s");
+    return train_step_impl(mdl, st, buf, adam, c, stream);
 }
 
 int mopoe_comm_status(mopoe_comm* c, int32_t* timeouts) {

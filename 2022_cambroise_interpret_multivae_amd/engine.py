@@ -228,11 +228,13 @@ class MoPoEEngine:
         return plan, ws
 
     def train_step(self, batch, eps=None, row_index=None, apply_adam=True,
-                   stats_host=None):
+                   stats_host=None, comm=None):
         """mopoe_train_step: forward + backward (+ fused Adam).  `stats_host`:
         a pinned host tensor the kernel writes the step's scalars into (the
         per-step log without a copy on the stream; read it after a sync or a
-        few steps later)."""
+        few steps later).  `comm` (an XgmiComm): mopoe_comm_train_step -- the
+        weight-gradient launch exchanges its blocks with the other ranks and
+        applies Adam with the mean (all ranks: same modalities in the batch)."""
         x, n, row_index = self._prepare(batch, row_index)
         plan = self.spec.plan(list(x.keys()), n, True, None, True, True)
         slots = max(plan.jobs_per_mod)
@@ -242,8 +244,15 @@ class MoPoEEngine:
         step.seed = self.seed
         buf = self._buffers(ws, x, row_index, stats_host, plan=plan)
         adam = C.byref(self.adam) if apply_adam else None
-        L.check(L.lib.mopoe_train_step(self.spec.c_model, step, buf, adam,
-                                       L.stream_ptr()), "mopoe_train_step")
+        if comm is not None:
+            if not apply_adam:
+                raise ValueError("the exchanging step applies Adam")
+            L.check(L.lib.mopoe_comm_train_step(comm._c, self.spec.c_model, step, buf,
+                                                adam, L.stream_ptr()),
+                    "mopoe_comm_train_step")
+        else:
+            L.check(L.lib.mopoe_train_step(self.spec.c_model, step, buf, adam,
+                                           L.stream_ptr()), "mopoe_train_step")
         self._keep = (x, keep, row_index)
         self.last_present_mask = step.present_mask
         self._host_step += 1

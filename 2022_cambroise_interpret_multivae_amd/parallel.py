@@ -27,14 +27,18 @@ def allreduce_mean_(flat_grads):
 class DataParallelStep:
     """engine.train_step + gradient all-reduce + engine.adam_step.
 
-    `comm`: an XgmiComm (comm.py) -- the exchange and the Adam update are then
-    ONE launch over the node's xGMI peer windows instead of the library
-    all-reduce followed by the Adam kernel; the sum is taken in rank order, so
-    replicas stay bit-identical."""
+    `comm`: an XgmiComm (comm.py) -- the exchange goes over the node's xGMI peer
+    windows instead of the library all-reduce, the sum is taken in rank order
+    (replicas stay bit-identical) and Adam rides in the same launch: inside the
+    weight-gradient launch itself (`in_backward=True`, the default: the N-rank
+    step has the two launches of the one-rank step; every rank's batch must hold
+    the same modalities), or as one launch after it (`in_backward=False`: any
+    mix of modality masks across ranks)."""
 
-    def __init__(self, engine, comm=None):
+    def __init__(self, engine, comm=None, in_backward=True):
         self.engine = engine
         self.comm = comm
+        self.in_backward = in_backward
         broadcast_parameters(engine.params)
         broadcast_parameters(engine.exp_avg)
         broadcast_parameters(engine.exp_avg_sq)
@@ -44,6 +48,8 @@ class DataParallelStep:
         world = dist.get_world_size() if dist.is_initialized() else 1
         if world == 1:
             return eng.train_step(batch, eps=eps, apply_adam=True)
+        if self.comm is not None and self.in_backward:
+            return eng.train_step(batch, eps=eps, apply_adam=True, comm=self.comm)
         out = eng.train_step(batch, eps=eps, apply_adam=False)
         if self.comm is not None:
             self.comm.allreduce_adam(eng)

@@ -198,6 +198,38 @@ def open_xgmi(num_floats, device, rank, world, dist):
     return comm, ""
 
 
+def check_in_backward(comm, spec, batch, device, world, dist):
+    """Two training steps with the exchange inside the weight-gradient launch
+    (mopoe_comm_train_step) must leave the same bits as the spelled-out form:
+    gradients gathered over the process group, added in rank order, Adam with 1/world."""
+    ok = 1.0
+    try:
+        a = mm.MoPoEEngine(spec, device, seed=99)
+        b = mm.MoPoEEngine(spec, device, seed=99)
+        for e in (a, b):
+            e.reset_parameters(torch.Generator().manual_seed(1))
+        for _ in range(2):
+            a.train_step(batch, apply_adam=True, comm=comm)
+            b.train_step(batch, apply_adam=False)
+            parts = [torch.empty_like(b.grads) for _ in range(world)]
+            dist.all_gather(parts, b.grads)
+            total = parts[0].clone()
+            for q in parts[1:]:
+                total += q
+            b.grads.copy_(total)
+            b.adam_step(grad_scale=1.0 / world)
+        torch.cuda.synchronize()
+        if not (torch.equal(a.params, b.params) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)):
+            ok = 0.0
+        if comm.timeouts():
+            ok = 0.0
+    except mm._lib.MopoeError:
+        ok = 0.0
+    flag = torch.tensor([ok], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return flag.item() == 1.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,7 +269,7 @@ def main():
     fused = dist is None
 
     # ---- the gradient exchange of the N-rank step
-    comm, exchange, why = None, "none", ""
+    comm, exchange, why, in_backward = None, "none", "", False
     if dist is not None:
         exchange = os.environ.get("MOPOE_EXCHANGE", "auto")
         if exchange not in ("auto", "xgmi", "rccl"):
@@ -247,10 +279,17 @@ def main():
             if comm is None and exchange == "xgmi":
                 sys.exit("MOPOE_EXCHANGE=xgmi but: " + why)
             exchange = "xgmi" if comm is not None else "rccl"
+        if comm is not None and os.environ.get("MOPOE_EXCHANGE_AFTER") is None:
+            in_backward = check_in_backward(comm, spec, pool[rank % POOL], device, world, dist)
+            if not in_backward:
+                why = "exchange inside the weight-gradient launch failed its start-up check"
 
     def step(i):
         # the step's scalar log lands in a ring of pinned host buffers, written
         # by the kernel itself (no copy on the stream)
+        if comm is not None and in_backward:
+            return eng.train_step(pool[(i * world + rank) % POOL], apply_adam=True, comm=comm,
+                                  stats_host=None if args.no_log_copy else log_ring[i % 8])[1]
         plan, ws = eng.train_step(pool[(i * world + rank) % POOL], apply_adam=fused,
                                   stats_host=None if args.no_log_copy else log_ring[i % 8])
         if comm is not None:
@@ -327,8 +366,12 @@ def main():
                    "parallelism": "dp%d" % world if dist is not None else "single",
                    "exchange": {"none": "none (single GPU: Adam fused into the "
                                         "weight-gradient launch)",
-                                "xgmi": "one launch per rank over xGMI peer windows: push "
-                                        "to every peer, rank-ordered sum, Adam",
+                                "xgmi": ("xGMI peer windows inside the weight-gradient launch: "
+                                         "every gradient block is pushed to every peer, summed "
+                                         "in rank order, Adam applied" if dist is not None and
+                                         comm is not None and in_backward else
+                                         "one launch per rank over xGMI peer windows: push "
+                                         "to every peer, rank-ordered sum, Adam"),
                                 "rccl": "RCCL all_reduce of the flat buffer + Adam kernel"
                                 }[exchange] + (" [%s]" % why if why else ""),
                    "host_log_every_step": not args.no_log_copy,
@@ -344,7 +387,7 @@ def main():
         torch.cuda.synchronize()
         prof = mm._lib.profile_read()
         mm._lib.profile_enable(False)
-        models = kernel_models(spec, BATCH, fused, world)
+        models = kernel_models(spec, BATCH, fused or in_backward, world)
         total_ms = sum(ms for _, ms in prof.values()) or 1.0
         name = max(prof, key=lambda k: prof[k][1])
         cnt, ms = prof[name]

@@ -289,6 +289,16 @@ int mopoe_adam_step(const mopoe_model* model, int32_t present_mask,
  *                       pushes, sums the copies in rank order (bit-identical on all
  *                       ranks), leaves the sum in buf->grads and applies Adam with
  *                       the mean.  All ranks must call it the same number of times.
+ *   mopoe_comm_train_step
+ *                       replaces `mopoe_train_step(adam = NULL); all_reduce(grads);
+ *                       mopoe_adam_step(1/world)`: mopoe_train_step whose
+ *                       weight-gradient launch exchanges every 32x32 gradient block
+ *                       with the peers (push, flag, wait, rank-ordered sum) between
+ *                       computing it and applying Adam with the mean -- the N-rank
+ *                       step has the same two launches as the one-rank step.  All
+ *                       ranks must step on batches with the SAME present_mask and the
+ *                       same batch-size class (n <= 512 or not): the blocks of the
+ *                       launch are matched by index.  buf->grads receives the sum.
  *   mopoe_comm_allreduce
  *                       the same exchange without the update: data (num_floats) is
  *                       replaced by the rank-ordered sum.
@@ -304,6 +314,9 @@ int mopoe_comm_allreduce(mopoe_comm* comm, float* data, void* stream);
 int mopoe_comm_allreduce_adam(mopoe_comm* comm, const mopoe_model* model,
                               int32_t present_mask, const mopoe_buffers* buf,
                               const mopoe_adam* adam, int32_t step, void* stream);
+int mopoe_comm_train_step(mopoe_comm* comm, const mopoe_model* model,
+                          const mopoe_step* step, const mopoe_buffers* buf,
+                          const mopoe_adam* adam, void* stream);
 int mopoe_comm_status(mopoe_comm* comm, int32_t* timeouts);
 int mopoe_comm_destroy(mopoe_comm* comm);
 

@@ -28,7 +28,13 @@ def test_exchange_and_fused_adam_between_processes(world):
                    # whole grid is resident, which other processes' grids on the same
                    # CUs break -- the ranks run the three-launch form here (same bits,
                    # tests/test_hip_fused.py); on the node every rank has its own GPU
-                   MOPOE_NO_FUSE="1")
+                   MOPOE_NO_FUSE="1",
+                   # the exchange INSIDE the weight-gradient launch is rehearsed with two
+                   # ranks only: its waiting workgroups hold most of a CU's registers,
+                   # and with three other ranks' launches waiting on the same GPU a
+                   # rank's 1024-thread row-group workgroups may find no CU to start on
+                   # (a circular wait over CUs that needs ranks sharing a GPU)
+                   XGMI_IN_BACKWARD="1" if world == 2 else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "xgmi_worker.py")],
                                       env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))

@@ -42,7 +42,8 @@ def main():
     torch.cuda.set_device(dev)
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    names, dims, style = ["clinical", "rois"], [7, 444], [3, 20]
+    names, style = ["clinical", "rois"], [3, 20]
+    dims = [int(d) for d in os.environ.get("XGMI_DIMS", "7,444").split(",")]
     spec = mm.ModelSpec(names, dims, style, class_dim=20, method="joint_elbo")
     eng = mm.MoPoEEngine(spec, dev, seed=77)
     eng.reset_parameters(torch.Generator().manual_seed(0))
@@ -133,7 +134,7 @@ def main():
     host_step = eng._host_step
     batches = [OrderedDict((k, torch.randn(64, d, generator=gx).to(dev))
                            for k, d in zip(names, dims)) for _ in range(20)]
-    step = parallel.DataParallelStep(eng, comm=comm)
+    step = parallel.DataParallelStep(eng, comm=comm, in_backward=False)
     for b in batches:
         step(b)
         torch.cuda.synchronize()
@@ -153,6 +154,43 @@ def main():
         raise SystemExit("rank %d: 20 back-to-back steps differ from the spelled-out form "
                          "(max %g, %d elements; %d timeouts)" % (
                              rank, d.max().item(), int((d > 0).sum()), comm.timeouts()))
+
+    # 4. the exchange inside the weight-gradient launch (mopoe_comm_train_step) against
+    #    the spelled-out form, from the same state: eight steps, the last one on a batch
+    #    without `clinical` (fewer blocks in the launch, same on all ranks)
+    eight = batches[:7] + [OrderedDict((k, v) for k, v in batches[7].items()
+                                       if k != "clinical")]
+
+    def restore(e):
+        for dst, src in zip((e.params, e.exp_avg, e.exp_avg_sq, e.counters), state):
+            dst.copy_(src)
+        e._host_step = host_step
+
+    if os.environ.get("XGMI_IN_BACKWARD", "1") == "0":
+        eight = []
+    restore(eng)
+    step = parallel.DataParallelStep(eng, comm=comm, in_backward=True)
+    for b in eight:
+        step(b)
+        torch.cuda.synchronize()
+        dist.barrier()
+    restore(ref)
+    for b in eight:
+        ref.train_step(b, apply_adam=False)
+        ref.grads.copy_(ordered_sum(gather_cpu(ref.grads)).to(dev))
+        ref.adam_step(grad_scale=1.0 / world)
+    torch.cuda.synchronize()
+    pairs = [("params", eng.params, ref.params), ("exp_avg", eng.exp_avg, ref.exp_avg),
+             ("exp_avg_sq", eng.exp_avg_sq, ref.exp_avg_sq)]
+    ga, gr = spec.param_views(eng.grads), spec.param_views(ref.grads)
+    pairs += [("grad of " + k, ga[k], gr[k]) for k in ga if "rois" in k]
+    for name, a, c in pairs:
+        if not torch.equal(a, c):
+            d = (a - c).abs()
+            raise SystemExit("rank %d: exchange inside the weight-gradient launch: %s differs "
+                             "from all-reduce + k_adam (max %g, %d elements; %d timeouts)" % (
+                                 rank, name, d.max().item(), int((d > 0).sum()),
+                                 comm.timeouts()))
     if comm.timeouts() != 0:
         raise SystemExit("rank %d: %d waits timed out" % (rank, comm.timeouts()))
     comm.close()
