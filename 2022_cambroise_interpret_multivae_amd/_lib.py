@@ -217,6 +217,33 @@ def require_gpu(t=None):
         raise MopoeError("expected a device tensor, got %s" % t.device)
 
 
+ROW_SLACK_BYTES = 16
+
+
+def rows_with_slack(t, device=None):
+    """`t` as a contiguous float32 device matrix whose storage stays readable for
+    ROW_SLACK_BYTES past the last row -- the contract of the input matrices in
+    include/mopoe_hip.h: the kernels read rows with 16-byte (k_wgrad: 8-byte) loads, and
+    when the row length is not a multiple of four the load that covers a row's tail
+    also covers the start of the next row; after the LAST row that is past the tensor
+    (values masked, but the bytes must be mapped: a tensor that ends exactly at the end
+    of an allocator segment would fault).  Returns `t` itself when it already qualifies."""
+    device = torch.device(device) if device is not None else t.device
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    ok = (t.device == device and t.dtype == torch.float32 and t.is_contiguous())
+    if ok and (t.dim() != 2 or t.shape[1] % 4 == 0):
+        return t
+    if ok:
+        slack = t.untyped_storage().nbytes() - (t.storage_offset() + t.numel()) * 4
+        if slack >= ROW_SLACK_BYTES:
+            return t
+    buf = torch.empty(t.numel() + ROW_SLACK_BYTES // 4, dtype=torch.float32, device=device)
+    out = buf[:t.numel()].view(t.shape)
+    out.copy_(t)
+    return out
+
+
 def profile_enable(on):
     check(lib.mopoe_profile_enable(int(bool(on))), "mopoe_profile_enable")
 

@@ -164,9 +164,7 @@ class MoPoEEngine:
         x = OrderedDict()
         n = None
         for name, v in batch.items():
-            t = v
-            if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
-                t = v.to(self.device, dtype=torch.float32).contiguous()
+            t = L.rows_with_slack(v, self.device)   # (v itself when it already qualifies)
             m = self.spec.names.index(name)
             if t.dim() != 2 or t.shape[1] != self.spec.input_dim[m]:
                 raise ValueError("batch[%r] has shape %s, expected (N, %d)" % (

@@ -22,6 +22,8 @@ from itertools import chain, combinations
 import numpy as np
 import torch
 
+from .. import _lib as L
+
 
 class MultimodalDataset(torch.utils.data.Dataset):
     def __init__(self, data, idx_per_mod, metadata=None, indices=None,
@@ -159,7 +161,7 @@ class ResidentCohort:
                 mean, scale = scalers[mod]
                 arr = (arr - torch.as_tensor(mean, dtype=torch.float64)) / \
                     torch.as_tensor(scale, dtype=torch.float64)
-            self.x[mod] = arr.to(torch.float32).to(self.device).contiguous()
+            self.x[mod] = L.rows_with_slack(arr.to(torch.float32), self.device)
         self._indices = None   # dataset.indices as an array, built on first use
         # block row of every subject, -1 where the modality is missing
         self.rows = {}

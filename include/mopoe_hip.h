@@ -171,7 +171,11 @@ typedef struct mopoe_buffers {
                                             launch timed out (results invalid),
                                             [3..10] Adam coefficients of step [0] */
 
-    const float* x[MOPOE_MAX_MODS];      /* (rows, d_m) input, ld = d_m        */
+    const float* x[MOPOE_MAX_MODS];      /* (rows, d_m) input, ld = d_m.  Must be
+                                            readable for 16 bytes past its last row:
+                                            rows are read with 16-byte loads, and with
+                                            d_m % 4 != 0 the load over a row's tail
+                                            also covers the next row's start (masked) */
     const int32_t* row_index[MOPOE_MAX_MODS]; /* optional (n) per modality: row of
                                             x[m] that holds batch row i (a batch
                                             is then a gather out of cohort arrays
@@ -324,7 +328,8 @@ int mopoe_comm_destroy(mopoe_comm* comm);
 
 /* torch.nn.Linear (+ optional ReLU) as used by Encoder.forward / Decoder.forward
  * (multimodal_cohort/networks/networks.py:30-36,66-77):
- * y (n, ncols) = act(x (n, k) @ w (ncols, k)^T + b). */
+ * y (n, ncols) = act(x (n, k) @ w (ncols, k)^T + b).  x as mopoe_buffers.x: readable
+ * for 16 bytes past its last row. */
 int mopoe_linear(const float* x, int32_t n, int32_t k, const float* w,
                  const float* b, int32_t ncols, int32_t relu, float* y,
                  void* stream);
