@@ -171,7 +171,7 @@ def open_xgmi(num_floats, device, rank, world, dist):
     inputs gathered over the process group.  Returns (comm, "") or (None, why)."""
     XgmiComm = mm.comm.XgmiComm
     try:
-        comm = XgmiComm(num_floats, timeout_ms=2000)
+        comm = XgmiComm(num_floats, timeout_ms=5000)
     except mm._lib.MopoeError as e:
         return None, "peer windows unavailable: %s" % e
     ok = 1.0
@@ -210,6 +210,8 @@ def check_in_backward(comm, spec, batch, device, world, dist):
         b = mm.MoPoEEngine(spec, device, seed=99)
         for e in (a, b):
             e.reset_parameters(torch.Generator().manual_seed(1))
+        torch.cuda.synchronize()
+        dist.barrier()          # ranks enter the first exchange together (bounded waits)
         for _ in range(2):
             a.train_step(batch, apply_adam=True, comm=comm)
             b.train_step(batch, apply_adam=False)
