@@ -640,6 +640,35 @@ DEV size_t xg_inbox(const XgPeers& x, int src) {
     return ((size_t)x.parity * x.world + src) * x.p4pad * 16;
 }
 
+// Plain stores through a descriptor: with `guard`ed offsets an invalid lane's store is
+// dropped by the hardware range check -- no branch around it, no 64-bit address
+// arithmetic (hipcc turns `if (ok) *p = v` into exec-mask juggling around a flat store).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEV void stg1(rsrc_t r, uint32_t off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, off, 0, 0);
+}
+DEV void stg2(rsrc_t r, uint32_t off, f32x2 v) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off, 0, 0);
+}
+DEV void stg4(rsrc_t r, uint32_t off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
+// NT (2 or 4) consecutive floats at float offset `o` of the buffer behind r, of which
+// `nvalid` (counted from the left, may be <= 0 or > NT) exist in the row; `ok`: the row
+// exists.  One vector store when all NT exist, single words otherwise; every store is
+// issued, the ones that do not apply go out of range.
+template <int NT, class V>
+DEV void stg_row(rsrc_t r, uint32_t o, V v, int nvalid, bool ok) {
+    if constexpr (NT == 4)
+        stg4(r, guard(o * 4u, ok & (nvalid >= 4)), v);
+    else
+        stg2(r, guard(o * 4u, ok & (nvalid >= 2)), v);
+#pragma unroll
+    for (int t = 0; t < NT - 1; ++t)
+        stg1(r, guard((o + t) * 4u, ok & (nvalid < NT) & (t < nvalid)), v[t]);
+}
+
 // B fragment of Y = A * W^T: W is (ncols, K) row-major with row stride ldw;
 // r covers ncols * ldw floats, so col >= ncols is out of range by itself.
 // VEC: K % 4 == 0 (then a 4-wide read never crosses a row end).

@@ -1387,7 +1387,16 @@ int validate(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* 
             return fail(MOPOE_ERR_ARG, "null forward buffer%s");
         if (train && (!buf->g_xhat[m] || !buf->g_heads[m] || !buf->g_pre[m]))
             return fail(MOPOE_ERR_ARG, "null backward buffer%s");
+        // the kernels address every per-row tensor with 32-bit byte offsets whose top bit
+        // marks an invalid lane: (decoder passes) * n * widest row must stay below 2 GiB
+        int njobs_m = 0;
+        for (int j = 0; j < st->num_jobs; ++j) njobs_m += st->job_mod[j] == m;
+        const long long widest = mdl->input_dim[m] > MOPOE_HIDDEN ? mdl->input_dim[m] : MOPOE_HIDDEN;
+        if ((long long)(njobs_m > 0 ? njobs_m : 1) * st->n * widest * 4 >= (1ll << 31))
+            return fail(MOPOE_ERR_ARG, "batch too large for 32-bit row offsets%s");
     }
+    if ((long long)st->num_subsets * st->n * mdl->class_dim * 4 >= (1ll << 31))
+        return fail(MOPOE_ERR_ARG, "batch too large for 32-bit row offsets%s");
     if (!buf->params || !buf->subsets_mu || !buf->subsets_logvar || !buf->joint_mu ||
         !buf->joint_logvar || !buf->stats || !buf->partials || !buf->counters)
         return fail(MOPOE_ERR_ARG, "null shared buffer%s");

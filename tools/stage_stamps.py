@@ -31,12 +31,20 @@ acc = None
 for it in range(40):
     plan, ws = eng.train_step(pool[it % 8])
     torch.cuda.synchronize()
-    st = ws._stats_all[64:64 + 24].cpu().view(torch.int32).view(12, 2).double()[used]
+    raw = ws._stats_all[64:64 + 30].cpu().view(torch.int32).view(15, 2).double()
+    st = raw[used]
     d = (st[1:] - st[:-1]) % 4294967296.0
     acc = d if acc is None else acc + d
+    # inside S3, wave 0: stamps 12 (MFMAs issued), 13 (rows done), 14 (at the barrier)
+    x = torch.stack([raw[12] - raw[4], raw[13] - raw[12], raw[14] - raw[13],
+                     raw[6] - raw[14]]) % 4294967296.0
+    inner = x if it == 0 else inner + x
 acc /= 40
+inner /= 40
 print("k_latent stage times, %s, N=%d (block 0)" % (method, n))
 for nme, row in zip(names, acc):
     rt, mt = row[0].item(), row[1].item()
     print("%-22s %6.2f us   clock %5.0f MHz" % (nme, rt / 100.0, (mt / rt * 100.0) if rt else 0))
 print("%-22s %6.2f us" % ("total", acc[:, 0].sum().item() / 100.0))
+print("inside S3 (wave 8): loads+MFMA issue %.2f | four rows of epilogue %.2f | sums %.2f | "
+      "waiting at the barrier %.2f us" % tuple(inner[:, 0] / 100.0))
