@@ -160,6 +160,10 @@ def main():
     #    without `clinical` (fewer blocks in the launch, same on all ranks)
     eight = batches[:7] + [OrderedDict((k, v) for k, v in batches[7].items()
                                        if k != "clinical")]
+    # one batch above 512 rows: the 8-wave form of the weight-gradient launch (half of its
+    # waves own no output and only keep the exchange's barriers company)
+    eight[3] = OrderedDict((k, torch.randn(600, d, generator=gx).to(dev))
+                           for k, d in zip(names, dims))
 
     def restore(e):
         for dst, src in zip((e.params, e.exp_avg, e.exp_avg_sq, e.counters), state):
