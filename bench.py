@@ -46,7 +46,7 @@ DIMS = [7, 444]
 STYLE = [3, 20]
 LATENT = 20
 BATCH = 256
-POOL = 64
+POOL = int(os.environ.get("MOPOE_BENCH_POOL", "64"))   # resident batches (a diagnostic knob; 64 is what is reported)
 HIDDEN = 256
 # MI355X_MICROARCH.md: exact-f32 MFMA peak = vector peak; HBM3E spec
 PEAK_F32_MFMA_TFLOPS = 157.3
