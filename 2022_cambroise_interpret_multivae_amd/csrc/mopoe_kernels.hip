@@ -116,6 +116,9 @@ struct LinGroup {
     const float* b;        // (ncols) or nullptr
     float* Y;              // (n, ncols), row stride ldy
     int32_t K, ldx, ncols, ldy, relu;
+    int32_t wslack;        // W stays readable 12 bytes past its end (a segment of the flat
+                           // parameter buffer): rows whose length is not a multiple of 4
+                           // are then read with 16-byte loads too
 };
 
 struct LinArgs {
@@ -197,6 +200,21 @@ DEV void adam_update(const AdamCoef& c, float g, float p, float m, float v, floa
     *po = p - c.step_size * (m1 / denom);                 // addcdiv_(m, denom, -step)
 }
 
+// Four consecutive floats of an input row starting at column k; columns >= Kc (the next
+// row's first values when the row length is not a multiple of 4, which the 16-byte load
+// picks up) become zeros.  One load, no branch -- with per-element loads the 7-column
+// modality's encoder tiles were the LAST producers of a row tile, by 2.3 us.
+DEV f32x4 ldg4_row(rsrc_t r, uint32_t base, bool ok, int k, int Kc) {
+    f32x4 v = ldg4(r, guard(base, ok & (k < Kc)));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float f = v[e];
+        v[e] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f) &
+                                             (k + e < Kc ? 0xFFFFFFFFu : 0u));
+    }
+    return v;
+}
+
 constexpr int kLinRedFloats = 4 * kWave * 4;  // partial tiles handed over through LDS
 
 // One workgroup = 4 waves = one 16-row tile x (4 / KS) column tiles of 16, the K axis
@@ -211,7 +229,7 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
     constexpr int CH = 8;      // W fragments per wave and batch
     constexpr int kStage = 8;  // float4 loads in flight per thread while staging
     const int N = a.n, K = g.K;
-    const bool vec = K % 4 == 0;   // 4-wide reads stay inside a row
+    const bool vec = K % 4 == 0 || g.wslack;   // W: 4-wide reads stay inside the buffer
     const int n0 = blockIdx.y * kRows;
     const int tile = wave / KS, part = wave % KS;
     const int j0 = (blockIdx.x * (4 / KS) + tile) * 16;
@@ -223,7 +241,7 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
         const int ldx = Kp + 4;
         const int q4 = Kp / 4;
         const int kend = j0 < g.ncols ? Kp : 0;
-        const rsrc_t wr = make_rsrc(g.W + kc0, (size_t)g.ncols * K * sizeof(float));
+        const rsrc_t wr = make_rsrc(g.W + kc0, ((size_t)g.ncols * K + (g.wslack ? 3 : 0)) * sizeof(float));
         // fragment i of this wave starts at k = 16 * (part + KS * i)
         auto load_w = [&](int i0, f32x4 (&b)[CH]) __attribute__((always_inline)) {
             if (vec) {  // (a select of the two forms would issue BOTH sets of loads)
@@ -247,13 +265,7 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
                 const bool rv = (s < kRows * q4) & (n0 + r < N);
                 const int row = rowsel ? rowsel[r] : min(n0 + r, N - 1);
                 const uint32_t base = (uint32_t)(row * g.ldx + kc0 + k) * 4u;
-                if (vec) {
-                    v[i] = ldg4(xr, guard(base, rv & (k < Kc)));
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[i][e] = ldg(xr, guard(base + 4u * e, rv & (k + e < Kc)));
-                }
+                v[i] = ldg4_row(xr, base, rv, k, Kc);
             }
             // the wave's first batch of W fragments goes out BEHIND the x loads (loads
             // return in order: requested first, it would hold the x tile -- and the
@@ -497,10 +509,10 @@ struct FArgs {
 // per block, a wave per column tile (more row tiles than the grid could hold otherwise)
 template <int KS>
 DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt, int cg,
-                        int tid, int lane, int wave, int32_t* flag) {
+                        int tid, int lane, int wave, int32_t* flag, int slot) {
     constexpr int CH = 8, kStage = 2, kTiles = kLatentWaves / KS, kCols = 16 * kTiles;
     const int N = a.n, K = g.K;
-    const bool vec = K % 4 == 0;
+    const bool vec = K % 4 == 0 || g.wslack;   // W: 4-wide reads stay inside the buffer
     const int n0 = rt * kRows;
     const int tile = wave / KS, part = wave % KS;
     const int j0 = (cg * kTiles + tile) * 16;
@@ -518,7 +530,7 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
         const int Kp = round_up(Kc, 16);
         const int ldx = Kp + 4;
         const int kend = j0 < g.ncols ? Kp : 0;
-        const rsrc_t wr = make_rsrc(g.W + kc0, (size_t)g.ncols * K * sizeof(float));
+        const rsrc_t wr = make_rsrc(g.W + kc0, ((size_t)g.ncols * K + (g.wslack ? 3 : 0)) * sizeof(float));
         auto load_w = [&](int i0, f32x4 (&b)[CH]) __attribute__((always_inline)) {
             if (vec) {
 #pragma unroll
@@ -545,13 +557,7 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
             for (int i = 0; i < kStage; ++i) {
                 const int k = (i * kWave + lane) * 4;
                 const uint32_t base = (uint32_t)(row * g.ldx + kc0 + k) * 4u;
-                if (vec) {
-                    v[i] = ldg4(xr, guard(base, rv & (k < Kc)));
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[i][e] = ldg(xr, guard(base + 4u * e, rv & (k + e < Kc)));
-                }
+                v[i] = ldg4_row(xr, base, rv, k, Kc);
             }
             load_w(0, b);  // behind the x loads (loads return in order)
 #pragma unroll
@@ -615,6 +621,9 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
             stg4_wt(yr, (uint32_t)(gn * g.ldy + col) * 4u, v);
         }
     }
+    // (diagnostic build: when each producer of row tile 0 has issued its stores;
+    //  tools/fused_handoff_timeline.py -- needs a counters buffer of 32 words)
+    GSTAMP(a.counters, 16 + slot * 4 + cg, a.counters && rt == 0 && tid == 0);
     // hand-off: every storing wave drains its stores, then ONE lane signals
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -642,11 +651,11 @@ __global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value
         if (f.ks == 4) {
             const int cg = b & 3, rt = (b >> 2) % f.row_tiles, z = (b >> 2) / f.row_tiles;
             int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * stride + kHandoffWord);
-            linear_block16<4>(a, a.g[z], lds, rt, cg, tid, lane, wave, flag);
+            linear_block16<4>(a, a.g[z], lds, rt, cg, tid, lane, wave, flag, z);
         } else {
             const int rt = b % f.row_tiles, z = b / f.row_tiles;
             int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * stride + kHandoffWord);
-            linear_block16<1>(a, a.g[z], lds, rt, 0, tid, lane, wave, flag);
+            linear_block16<1>(a, a.g[z], lds, rt, 0, tid, lane, wave, flag, z);
         }
         return;
     }
@@ -1469,6 +1478,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         g.ncols = kHid;
         g.ldy = kHid;
         g.relu = 1;
+        g.wslack = 1;   // W1 is a segment of the flat buffer, b1 follows it
     }
     int lds = ka.lds.total * (int)sizeof(float);
     if (lds > 160 * 1024)

@@ -65,7 +65,7 @@ class MoPoEEngine:
         self.grads = torch.zeros(P, **f)
         self.exp_avg = torch.zeros(P, **f)
         self.exp_avg_sq = torch.zeros(P, **f)
-        self.counters = torch.zeros(16, dtype=torch.int32, device=self.device)
+        self.counters = torch.zeros(32, dtype=torch.int32, device=self.device)   # (16 + diagnostic stamps)
         self.device = self.params.device   # with its index: cheap `is it already there` tests
         self.views = spec.param_views(self.params)
         self.grad_views = spec.param_views(self.grads)
