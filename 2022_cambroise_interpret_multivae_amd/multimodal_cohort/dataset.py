@@ -156,7 +156,7 @@ class ResidentCohort:
         self.device = torch.device(device)
         self.x = {}
         for mod in dataset.modalities:
-            arr = torch.as_tensor(np.ascontiguousarray(dataset.data[mod]), dtype=torch.float64)
+            arr = torch.as_tensor(np.array(dataset.data[mod], dtype=np.float64, order="C"))  # (a copy: the block may be a read-only memory map)
             if scalers is not None and mod in scalers:
                 mean, scale = scalers[mod]
                 arr = (arr - torch.as_tensor(mean, dtype=torch.float64)) / \
