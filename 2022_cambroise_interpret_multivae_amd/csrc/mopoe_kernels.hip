@@ -1625,6 +1625,8 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
     if (comm) comm_next(comm, xg);
     build_wargs(ka, adam, w, comm ? &xg : nullptr);
     const dim3 grid(w.total_tiles + w.lvo_blocks + 1);
+    if (comm && (int)grid.x > xg.flag_stride)   // one arrival flag per exchanging workgroup
+        return fail(MOPOE_ERR_ARG, "more weight-gradient blocks than the communicator has flags%s");
     {
         ProfScope ps(MOPOE_KERNEL_WGRAD, s);
         if (ka.st.n > 512) {
