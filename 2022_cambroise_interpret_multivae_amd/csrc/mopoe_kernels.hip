@@ -1599,6 +1599,7 @@ int build_adam_segs(const mopoe_model& mdl, int32_t present_mask, const mopoe_ad
 }
 
 void comm_next(mopoe_comm* c, XgPeers& x);
+int comm_flag_stride(const mopoe_comm* c);
 int comm_check(const mopoe_comm* c, const mopoe_model* mdl);
 
 int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* buf,
@@ -1619,14 +1620,15 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
     latent_lds_layout(ka.mdl, ka.st, kLatentWaves, ka.lds);
     latent_bind(ka.lds, ka.buf);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (int rc = launch_forward_part(ka, adam, s)) return rc;
     WArgs w;
-    XgPeers xg;
-    if (comm) comm_next(comm, xg);
-    build_wargs(ka, adam, w, comm ? &xg : nullptr);
+    build_wargs(ka, adam, w);
     const dim3 grid(w.total_tiles + w.lvo_blocks + 1);
-    if (comm && (int)grid.x > xg.flag_stride)   // one arrival flag per exchanging workgroup
+    // (checked before anything is launched: a refused call leaves no half step behind and
+    //  does not advance the exchange's sequence number)
+    if (comm && (int)grid.x > comm_flag_stride(comm))   // one arrival flag per exchanging workgroup
         return fail(MOPOE_ERR_ARG, "more weight-gradient blocks than the communicator has flags%s");
+    if (int rc = launch_forward_part(ka, adam, s)) return rc;
+    if (comm) comm_next(comm, w.xg);
     {
         ProfScope ps(MOPOE_KERNEL_WGRAD, s);
         if (ka.st.n > 512) {
