@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Diagnostic: where the host time of an epoch over a ResidentCohort goes (16 k synthetic
+subjects, batch 256): dataset.epoch() and its sampler, engine.train_step's enqueue cost per
+call, and a cProfile of the step loop."""
 import os, sys, time
-root = "/root/repo"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [root, os.path.join(root, "tests"), os.path.join(root, "oracle")]
 import numpy as np, torch
 from importlib import import_module
