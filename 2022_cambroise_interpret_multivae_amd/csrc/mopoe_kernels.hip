@@ -630,6 +630,7 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
     if (tid == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <bool LEAN>
 __global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value) {
     (void)f_by_value;  // read in place (see k_latent)
     const FArgs& f = *(const FArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value
     }
     const int grp = b - f.nlin;
     int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)grp * stride + kHandoffWord);
-    latent_body<true>(f.ka, lds, grp, flag, f.ks * f.la.ngroups);
+    latent_body<true, LEAN>(f.ka, lds, grp, flag, f.ks * f.la.ngroups);
 }
 
 // Scalars of the step from the row tiles' partial sums, in a fixed order
@@ -1497,8 +1498,11 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         const int lin_lds = (kRows + kRows * (kp + 4) + (ks == 4 ? 4 * kRows * 68 : kRows * 260)) * (int)sizeof(float);
         if (lin_lds > lds) lds = lin_lds;
         if (lds > 64 * 1024 && lds > lds_opted_f) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return fail(MOPOE_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
             lds_opted_f = lds;
         }
@@ -1510,7 +1514,16 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         fa.ks = ks;
         {
             ProfScope ps(MOPOE_KERNEL_FUSED, s);
-            hipLaunchKernelGGL(k_fused, dim3(nlin + row_tiles), dim3(kLatentThreads), (size_t)lds, s, fa);
+            // the lean instantiation for the common training case (see latent_body)
+            bool lean = ka.st.backward && ka.st.sample && ka.lds.single_pass && ka.lds.s3_nt == 2 &&
+                        ka.lds.xs_early && ka.st.joint_mode == MOPOE_JOINT_MIXTURE &&
+                        getenv("MOPOE_NO_LEAN") == nullptr;
+            for (int k = 0; k < ka.st.num_subsets; ++k)
+                lean = lean && ka.st.sub_kind[k] != MOPOE_SUB_SLICES;
+            if (lean)
+                hipLaunchKernelGGL(k_fused<true>, dim3(nlin + row_tiles), dim3(kLatentThreads), (size_t)lds, s, fa);
+            else
+                hipLaunchKernelGGL(k_fused<false>, dim3(nlin + row_tiles), dim3(kLatentThreads), (size_t)lds, s, fa);
         }
         return check_launch("k_fused");
     }
