@@ -1515,7 +1515,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         {
             ProfScope ps(MOPOE_KERNEL_FUSED, s);
             // the lean instantiation for the common training case (see latent_body)
-            bool lean = ka.st.backward && ka.st.sample && ka.lds.single_pass && ka.lds.s3_nt == 2 &&
+            bool lean = mdl.num_mods <= 2 && ka.st.backward && ka.st.sample && ka.lds.single_pass && ka.lds.s3_nt == 2 &&
                         ka.lds.xs_early && ka.st.joint_mode == MOPOE_JOINT_MIXTURE &&
                         getenv("MOPOE_NO_LEAN") == nullptr;
             for (int k = 0; k < ka.st.num_subsets; ++k)
