@@ -432,7 +432,8 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
 
 // Rows per k_latent group: 16 (one full MFMA tile) whenever the carve-up fits the LDS,
 // else the largest of 8, 4, 2, 1 that does (wide inputs, five modalities: the MFMA
-// tiles then run partly empty, which costs nothing -- no stage is MFMA-bound).
+// tiles then run partly empty -- a group of R < 16 rows issues as many MFMAs as one of
+// 16, so the GEMM stages take the same time for fewer rows).
 // mopoe_step.rows_per_group pins it (tests exercise the small-group path that way).
 HD void latent_lds_layout(const mopoe_model& m, const mopoe_step& st, int waves,
                           LatentLds& L) {
