@@ -69,6 +69,25 @@ CASES = [
          factorized=True, N=512, steps=2, full=False),
 ]
 
+# Cases added after the first fixture set (their files are new; the ones above are
+# regenerated bit-identically).  `present_steps`: the batch of step k holds only these
+# modalities -- what MissingModalitySampler feeds the loop (dataset.py:275-354).
+# torch.optim.Adam keeps state['step'] per parameter and skips parameters whose grad
+# is None, so an encoder / decoder that sat out k steps is k Adam steps behind.
+CASES += [
+    dict(case="c1_joint_mixed_masks_n24", **C1, method="joint_elbo",
+         factorized=True, N=24, steps=6, full=False, every_step=True,
+         present_steps=[["clinical", "rois"], ["clinical"], ["clinical", "rois"],
+                        ["rois"], ["rois"], ["clinical", "rois"]]),
+    dict(case="c5_4mod_mixed_masks_n20", **C5, method="joint_elbo",
+         factorized=True, N=20, steps=4, full=False, every_step=True,
+         present_steps=[["clinical", "rois", "snps", "tracts"], ["clinical", "snps"],
+                        ["rois"], ["clinical", "rois", "snps", "tracts"]]),
+    # run_epochs.py:115: method poe without the unimodal ELBOs
+    dict(case="c3_poe_nounimodal_n16", **C1, method="poe", factorized=True, N=16,
+         steps=2, full=True, poe_unimodal_elbos=False),
+]
+
 # forward-only variants (BaseMMVae.forward flags), on the c1 model
 FWD_CASES = [
     dict(case="fwd_c1_nosample_n16", **C1, method="joint_elbo",
@@ -116,10 +135,12 @@ def build(ns, c, seed=0):
     flags = rh.make_flags(c["input_dim"],
                           mo.Config(c["names"], c["input_dim"], c["style_dim"],
                                     factorized=c["factorized"]).style_dim,
-                          method=c["method"], factorized=c["factorized"])
+                          method=c["method"], factorized=c["factorized"],
+                          poe_unimodal_elbos=c.get("poe_unimodal_elbos", True))
     exp = rh.build_experiment(ns, flags, c["names"])
     cfg = mo.Config(c["names"], c["input_dim"], c["style_dim"],
-                    method=c["method"], factorized=c["factorized"])
+                    method=c["method"], factorized=c["factorized"],
+                    poe_unimodal_elbos=c.get("poe_unimodal_elbos", True))
     init = mo.init_params(cfg, seed)
     missing, unexpected = exp.models.load_state_dict(init, strict=True)
     assert not missing and not unexpected
@@ -181,7 +202,9 @@ def run_case(ns, c):
             store["in/x/" + k] = np32(v)
     for step in range(c["steps"]):
         tape = rh.NoiseTape(model, generator=mo.noise_rng(4321 + step))
-        batch = (OrderedDict((k, v.double()) for k, v in x.items()), None, {})
+        present = c["present_steps"][step] if "present_steps" in c else list(x)
+        batch = (OrderedDict((k, v.double()) for k, v in x.items() if k in present),
+                 None, {})
         out = ns.run_epochs.basic_routine_epoch(exp, 0, batch)
         for i, e in enumerate(tape.tape):
             store["noise_checksum/%d/%d" % (step, i)] = checksum(e)
@@ -198,8 +221,11 @@ def run_case(ns, c):
                 [k for k, p in model.named_parameters() if p.grad is None]))
         else:
             store["step%d/total_loss" % step] = np32(out["total_loss"])
+        if c.get("every_step"):
+            store["step%d/grad_none" % step] = np.array(json.dumps(
+                [k for k, p in model.named_parameters() if p.grad is None]))
         opt.step()
-        if step in (0, c["steps"] - 1):
+        if step in (0, c["steps"] - 1) or c.get("every_step"):
             put_digest(store, "after%d/params" % (step + 1),
                        OrderedDict(model.named_parameters()))
     st = opt.state_dict()["state"]
@@ -208,6 +234,10 @@ def run_case(ns, c):
         (names[i], s["exp_avg"]) for i, s in st.items()))
     put_digest(store, "final/exp_avg_sq", OrderedDict(
         (names[i], s["exp_avg_sq"]) for i, s in st.items()))
+    # torch's per-parameter step counts (a parameter never stepped has no state)
+    if c.get("every_step"):
+        store["final/adam_steps"] = np.array(json.dumps(
+            {names[i]: int(s["step"]) for i, s in st.items()}))
     return store
 
 
@@ -309,6 +339,16 @@ def main():
     ns = rh.import_reference()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     total = 0
+    only = sys.argv[1:]            # optional: case names to (re)generate
+    if only:
+        for c in CASES:
+            if c["case"] in only:
+                store = run_case(ns, c)
+                path = os.path.join(GOLDEN_DIR, c["case"] + ".npz")
+                np.savez_compressed(path, **store)
+                print("%-32s %8d B  loss=%s" % (c["case"], os.path.getsize(path),
+                                                store["step0/total_loss"]))
+        return
     for c in CASES:
         store = run_case(ns, c)
         path = os.path.join(GOLDEN_DIR, c["case"] + ".npz")

@@ -37,7 +37,7 @@ class Config:
                  method="joint_elbo", factorized=True, beta=1.0,
                  beta_style=1.0, beta_content=1.0, initial_out_logvar=-3.0,
                  learn_output_scale=True, lr=0.002, betas=(0.9, 0.999),
-                 adam_eps=1e-8):
+                 adam_eps=1e-8, poe_unimodal_elbos=True):
         assert method in ("joint_elbo", "poe", "moe")
         self.names = list(names)
         self.input_dim = list(input_dim)
@@ -60,6 +60,9 @@ class Config:
         self.lr = lr
         self.betas = betas
         self.adam_eps = adam_eps
+        # experiments/run_epochs.py:115: method poe adds the unimodal ELBOs (and
+        # their extra forwards) only when this flag is set
+        self.poe_unimodal_elbos = poe_unimodal_elbos
         # float32 is the reference's arithmetic; tests also run the oracle in
         # float64 to measure how much float32 rounding alone moves a result
         self.dtype = torch.float32
@@ -472,6 +475,8 @@ def basic_routine_epoch(params, cfg, batch, noise):
             else:
                 kld_style_m = 0.0
             klds_joint["style"][name] = kld_style_m
+            if not cfg.poe_unimodal_elbos:      # run_epochs.py:115
+                continue
             r_mod = forward(params, cfg, {name: batch[name]}, noise)
             loc, scale = r_mod["rec"][name]
             log_prob_mod = -calc_log_prob(loc, scale, batch[name],
@@ -492,7 +497,10 @@ def basic_routine_epoch(params, cfg, batch, noise):
 # optimiser (torch.optim.Adam semantics; experiment.py:256-279)
 # --------------------------------------------------------------------------
 def adam_init(params):
-    return {"step": 0,
+    """torch.optim.Adam keeps state per parameter, `step` included: a parameter
+    whose .grad is None in a step (its modality was not in the batch) is
+    skipped and its step count does not advance."""
+    return {"step": OrderedDict((k, 0) for k in params),
             "exp_avg": OrderedDict((k, torch.zeros_like(v))
                                    for k, v in params.items()),
             "exp_avg_sq": OrderedDict((k, torch.zeros_like(v))
@@ -501,18 +509,22 @@ def adam_init(params):
 
 def adam_step(cfg, params, grads, state):
     """In-place torch.optim.Adam (amsgrad False, weight_decay 0,
-    maximize False): p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)."""
+    maximize False): p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),
+    t = the PARAMETER's own step count (torch keeps state['step'] per
+    parameter and skips parameters without a gradient)."""
     b1, b2 = cfg.betas
-    state["step"] += 1
-    t = state["step"]
-    bc1 = 1 - b1 ** t
-    bc2 = 1 - b2 ** t
-    step_size = cfg.lr / bc1
-    bc2_sqrt = math.sqrt(bc2)
+    if not isinstance(state["step"], dict):     # one count for all: same t everywhere
+        state["step"] = OrderedDict((k, state["step"]) for k in params)
     for name, p in params.items():
         g = grads.get(name)
         if g is None:
             continue
+        state["step"][name] += 1
+        t = state["step"][name]
+        bc1 = 1 - b1 ** t
+        bc2 = 1 - b2 ** t
+        step_size = cfg.lr / bc1
+        bc2_sqrt = math.sqrt(bc2)
         m = state["exp_avg"][name]
         v = state["exp_avg_sq"][name]
         m.lerp_(g, 1 - b1)

@@ -104,7 +104,8 @@ def import_reference():
 
 def make_flags(input_dim, style_dim, class_dim=20, method="joint_elbo",
                factorized=True, beta=1.0, beta_style=1.0, beta_content=1.0,
-               batch_size=256, initial_out_logvar=-3.0, learn_output_scale=True):
+               batch_size=256, initial_out_logvar=-3.0, learn_output_scale=True,
+               poe_unimodal_elbos=True):
     """SimpleNamespace mirroring what workflow.train_exp builds
     (reference experiments/workflow.py:98-145)."""
     M = len(input_dim)
@@ -114,7 +115,7 @@ def make_flags(input_dim, style_dim, class_dim=20, method="joint_elbo",
         factorized_representation=factorized, input_dim=list(input_dim),
         joint_elbo=(method == "joint_elbo"), modality_jsd=False,
         modality_moe=(method == "moe"), modality_poe=(method == "poe"),
-        poe_unimodal_elbos=True, num_hidden_layer_encoder=1,
+        poe_unimodal_elbos=poe_unimodal_elbos, num_hidden_layer_encoder=1,
         num_hidden_layer_decoder=0, dropout_rate=0.0,
         initial_out_logvar=initial_out_logvar,
         learn_output_scale=learn_output_scale,

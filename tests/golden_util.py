@@ -32,11 +32,15 @@ class Fixture:
         self.meta = json.loads(str(self.z["meta"]))
         m = self.meta
         self.cfg = mo.Config(m["names"], m["input_dim"], m["style_dim"],
-                             method=m["method"], factorized=m["factorized"])
+                             method=m["method"], factorized=m["factorized"],
+                             poe_unimodal_elbos=m.get("poe_unimodal_elbos", True))
         self.N = m["N"]
         self.steps = m.get("steps", 1)
         self.full = m.get("full", True)
         self.present = m.get("present") or m["names"]
+        # batches whose modality set changes from step to step (mixed-mask cases)
+        self.present_steps = m.get("present_steps")
+        self.every_step = bool(m.get("every_step"))
 
     def keys(self, prefix):
         return [k for k in self.z.files if k.startswith(prefix)]
@@ -61,6 +65,15 @@ class Fixture:
                 assert abs(f.sum().item() - cs[0]) < 1e-6 * max(1, abs(cs[0]))
                 assert abs(f.abs().sum().item() - cs[1]) < 1e-6 * cs[1]
         return x
+
+    def inputs_at(self, step):
+        """The batch of step `step`: the case's inputs restricted to the modalities
+        that step's batch holds."""
+        x = self.inputs()
+        if self.present_steps is None:
+            return x
+        return OrderedDict((k, v) for k, v in x.items()
+                           if k in self.present_steps[step])
 
     def noise_seed(self, step):
         return (7 if self.case.startswith("fwd_") else 4321 + step)

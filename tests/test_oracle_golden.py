@@ -74,11 +74,14 @@ def test_train_steps_match_reference(case):
     cfg = fx.cfg
     params = mo.init_params(cfg, 0)
     state = mo.adam_init(params)
-    x = fx.inputs()
     for step in range(fx.steps):
+        x = fx.inputs_at(step)
         noise = fx.noise(step)
         out, grads = mo.train_step(params, cfg, x, noise, state)
         fx.check_noise(step, noise)
+        if fx.every_step:   # which parameters torch left without a gradient
+            none = json.loads(str(fx.z["step%d/grad_none" % step]))
+            assert sorted(none) == sorted(set(params) - set(grads))
         if step == 0:
             compare_results(fx, out)
             none = json.loads(str(fx.z["step0/grad_none"]))
@@ -87,9 +90,12 @@ def test_train_steps_match_reference(case):
         else:
             assert_close(out["total_loss"],
                          fx.get("step%d/total_loss" % step), 1e-5, 1e-6)
-        if step in (0, fx.steps - 1):
+        if step in (0, fx.steps - 1) or fx.every_step:
             check_digests(fx, "after%d/params" % (step + 1), params,
                           1e-6 if step == 0 else 1e-4, 1e-6)
+    if fx.every_step:       # torch's per-parameter Adam step counts
+        want = json.loads(str(fx.z["final/adam_steps"]))
+        assert {k: v for k, v in state["step"].items() if v} == want
     touched = OrderedDict((k, v) for k, v in state["exp_avg"].items()
                           if fx.has("final/exp_avg/" + k + "/stats"))
     # several steps of Adam amplify 1-ulp differences in early gradients
