@@ -13,7 +13,7 @@ MAX_SUBSETS = 31
 MAX_JOBS = 10
 HIDDEN = 256
 ROWS = 16
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_RANKS = 8
 IPC_HANDLE_BYTES = 64
 
@@ -25,7 +25,12 @@ STAT_JOINT_DIV = 1
 STAT_KLD_SUBSET = 2
 STAT_KLD_STYLE = 2 + MAX_SUBSETS
 STAT_NLL = STAT_KLD_STYLE + MAX_MODS
-NUM_STATS = STAT_NLL + MAX_JOBS
+STAT_LATENT_MEAN = STAT_NLL + MAX_JOBS    # + 4 * modality + {style mu, style lv, mu, lv}
+NUM_STATS = STAT_LATENT_MEAN + 4 * MAX_MODS
+STATS_ALLOC = 256          # floats of a stats buffer ([128:] diagnostic stamps)
+NUM_COUNTERS = 64
+COUNTERS_ALLOC = 128       # ints of a counters buffer ([64:] diagnostic stamps)
+CTR_STEPS_BEGUN, CTR_STEPS_DONE, CTR_INVALID, CTR_ADAM_STEPS = 0, 1, 2, 4
 KERNEL_NAMES = ("k_linear", "k_latent", "k_wgrad", "k_adam", "k_finalize", "k_fused",
                 "k_xgmi")
 
@@ -49,6 +54,7 @@ class Model(C.Structure):
         ("off_wd", _i32 * MAX_MODS),
         ("off_bd", _i32 * MAX_MODS),
         ("off_lvo", _i32 * MAX_MODS),
+        ("off_ctrl", _i32),
         ("num_floats", _i32),
     ]
 
@@ -96,6 +102,7 @@ class Buffers(C.Structure):
         ("counters", _ptr),
         ("x", _ptr * MAX_MODS),
         ("row_index", _ptr * MAX_MODS),
+        ("x_rows", _i32 * MAX_MODS),
         ("hidden", _ptr * MAX_MODS),
         ("heads", _ptr * MAX_MODS),
         ("subsets_mu", _ptr),
@@ -106,6 +113,7 @@ class Buffers(C.Structure):
         ("loc", _ptr * MAX_MODS),
         ("stats", _ptr),
         ("stats_host", _ptr),
+        ("status_host", _ptr),
         ("g_xhat", _ptr * MAX_MODS),
         ("g_heads", _ptr * MAX_MODS),
         ("g_pre", _ptr * MAX_MODS),
@@ -137,13 +145,12 @@ SYMBOLS = {
     "mopoe_train_step": (C.c_int, [C.POINTER(Model), C.POINTER(Step),
                                    C.POINTER(Buffers), C.POINTER(Adam), _ptr]),
     "mopoe_adam_step": (C.c_int, [C.POINTER(Model), _i32, C.POINTER(Buffers),
-                                  C.POINTER(Adam), _f32, _i32, _ptr]),
+                                  C.POINTER(Adam), _i32, _ptr]),
     "mopoe_comm_create": (C.c_int, [_i32, _i32, _i32, _i32, C.POINTER(_ptr), _ptr]),
     "mopoe_comm_connect": (C.c_int, [_ptr, _ptr]),
     "mopoe_comm_allreduce": (C.c_int, [_ptr, _ptr, _ptr]),
     "mopoe_comm_allreduce_adam": (C.c_int, [_ptr, C.POINTER(Model), _i32,
-                                            C.POINTER(Buffers), C.POINTER(Adam), _i32,
-                                            _ptr]),
+                                            C.POINTER(Buffers), C.POINTER(Adam), _ptr]),
     "mopoe_comm_train_step": (C.c_int, [_ptr, C.POINTER(Model), C.POINTER(Step),
                                         C.POINTER(Buffers), C.POINTER(Adam), _ptr]),
     "mopoe_comm_status": (C.c_int, [_ptr, C.POINTER(_i32)]),
@@ -179,7 +186,8 @@ def _load():
     mirrors = [C.sizeof(Model), C.sizeof(Step), C.sizeof(Buffers),
                C.sizeof(Adam), Step.job_eps_content.offset,
                Step.comp_w.offset, Buffers.partials.offset,
-               Model.num_floats.offset]
+               Model.num_floats.offset, Buffers.status_host.offset,
+               Model.off_ctrl.offset]
     for which, mine in enumerate(mirrors):
         if lib.mopoe_sizeof(which) != mine:
             raise ImportError("ctypes mirror %d disagrees with the C struct "
@@ -217,31 +225,18 @@ def require_gpu(t=None):
         raise MopoeError("expected a device tensor, got %s" % t.device)
 
 
-ROW_SLACK_BYTES = 16
-
-
-def rows_with_slack(t, device=None):
-    """`t` as a contiguous float32 device matrix whose storage stays readable for
-    ROW_SLACK_BYTES past the last row -- the contract of the input matrices in
-    include/mopoe_hip.h: the kernels read rows with 16-byte (k_wgrad: 8-byte) loads, and
-    when the row length is not a multiple of four the load that covers a row's tail
-    also covers the start of the next row; after the LAST row that is past the tensor
-    (values masked, but the bytes must be mapped: a tensor that ends exactly at the end
-    of an allocator segment would fault).  Returns `t` itself when it already qualifies."""
+def device_rows(t, device=None):
+    """`t` as a contiguous float32 matrix on `device` (itself when it already is one).
+    The kernels read an input matrix through a descriptor of exactly rows * d floats:
+    nothing beyond the tensor is touched, whatever its row length or where its storage
+    ends (the 16-byte load over the tail of the last row is masked by the hardware's
+    per-dword range check)."""
     device = torch.device(device) if device is not None else t.device
     if device.type == "cuda" and device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    ok = (t.device == device and t.dtype == torch.float32 and t.is_contiguous())
-    if ok and (t.dim() != 2 or t.shape[1] % 4 == 0):
+    if t.device == device and t.dtype == torch.float32 and t.is_contiguous():
         return t
-    if ok:
-        slack = t.untyped_storage().nbytes() - (t.storage_offset() + t.numel()) * 4
-        if slack >= ROW_SLACK_BYTES:
-            return t
-    buf = torch.empty(t.numel() + ROW_SLACK_BYTES // 4, dtype=torch.float32, device=device)
-    out = buf[:t.numel()].view(t.shape)
-    out.copy_(t)
-    return out
+    return t.to(device=device, dtype=torch.float32).contiguous()
 
 
 def profile_enable(on):

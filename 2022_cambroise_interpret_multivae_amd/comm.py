@@ -68,9 +68,10 @@ class XgmiComm:
         b.exp_avg = L.ptr(engine.exp_avg)
         b.exp_avg_sq = L.ptr(engine.exp_avg_sq)
         b.counters = L.ptr(engine.counters)
+        b.status_host = L.ptr(engine.status_host)
         L.check(L.lib.mopoe_comm_allreduce_adam(
             self._c, engine.spec.c_model, present_mask, b, C.byref(engine.adam),
-            engine._host_step, L.stream_ptr()), "mopoe_comm_allreduce_adam")
+            L.stream_ptr()), "mopoe_comm_allreduce_adam")
 
     def timeouts(self):
         """Waits that ran out of their budget so far (0 = every exchange was

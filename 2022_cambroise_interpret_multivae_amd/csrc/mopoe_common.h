@@ -16,7 +16,7 @@ constexpr int kWave = 64;            // CDNA4 wavefront
 constexpr int kRows = MOPOE_ROWS;    // batch rows per tile = MFMA M
 constexpr int kHid = MOPOE_HIDDEN;
 constexpr int kLdH = kHid + 4;       // LDS leading dim of a hidden tile
-constexpr int kStatStride = 64;      // floats reserved for scalar partials
+constexpr int kStatStride = 96;      // floats reserved for scalar partials
 constexpr int kGzChunks = 4;         // K-split of the decoder data-gradient GEMM
 constexpr int kEncKChunk = 512;      // K chunk of the encoder input tile in LDS
 
@@ -24,8 +24,10 @@ constexpr int kEncKChunk = 512;      // K chunk of the encoder input tile in LDS
 constexpr int kPartKlSub = 0;                         // + subset
 constexpr int kPartKlStyle = MOPOE_MAX_SUBSETS;       // + modality
 constexpr int kPartNll = kPartKlStyle + MOPOE_MAX_MODS;  // + job
-constexpr int kNumPart = kPartNll + MOPOE_MAX_JOBS;
-static_assert(kNumPart <= kStatStride, "partials overflow their slot");
+constexpr int kPartMean = kPartNll + MOPOE_MAX_JOBS;  // + 4 * modality + {style mu, style lv, mu, lv}
+constexpr int kNumPart = kPartMean + 4 * MOPOE_MAX_MODS;
+constexpr int kHandoffWord = kStatStride - 1;  // word of a group's partial slab used as its flag
+static_assert(kNumPart < kHandoffWord, "partials overflow their slot");
 
 HD int round_up(int v, int m) { return (v + m - 1) / m * m; }
 HD int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -606,32 +608,40 @@ struct XgPeers {
     uint32_t seq, parity, timeout_ticks;
     int32_t flag_stride;                 // flag words per source rank
     float inv_world;
-    int32_t pad;
+    int32_t mask;                        // modalities in this rank's batch (0 when the
+                                         // exchange is a plain all-reduce)
     size_t p4pad;                        // float4 per (parity, source) inbox
     size_t flags_off, status_off;        // byte offsets inside a window
     void* window[MOPOE_MAX_RANKS];       // base of every rank's window as mapped HERE
 };
 
-// Publishes `seq` in flags[me][slot] of every peer, then waits (bounded) until every
-// peer's flags[peer][slot] HERE has reached it.  Called by the threads tid < world of a
-// workgroup (or wave) whose pushes have drained (s_waitcnt vmcnt(0) + barrier).
-DEV void xg_signal_and_wait(const XgPeers& x, int tid, int slot) {
-    if (tid >= x.world || tid == x.rank) return;
+// Publishes (seq, present_mask) in flags[me][slot] of every peer, then waits (bounded)
+// until every peer's flags[peer][slot] HERE has reached seq.  Called by the threads
+// tid < world of a workgroup (or wave) whose pushes have drained (s_waitcnt vmcnt(0) +
+// barrier).  A flag word is seq << 8 | mask: the ranks' batches must hold the same
+// modalities (the sum of gradients of different parameter sets is not a step of the
+// reference), and a rank learns its peers' masks from the very word it waits for.
+// Returns true when the exchange is NOT good: a wait ran out of its budget (also counted
+// in the window's status word) or a peer's batch held other modalities.
+DEV bool xg_signal_and_wait(const XgPeers& x, int tid, int slot) {
+    if (tid >= x.world || tid == x.rank) return false;
     uint32_t* out = reinterpret_cast<uint32_t*>(static_cast<char*>(x.window[tid]) + x.flags_off) +
                     (size_t)x.rank * x.flag_stride + slot;
-    __hip_atomic_store(out, x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t want = x.seq << 8;
+    __hip_atomic_store(out, want | ((uint32_t)x.mask & 0xFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t* in = reinterpret_cast<const uint32_t*>(
                              static_cast<const char*>(x.window[x.rank]) + x.flags_off) +
                          (size_t)tid * x.flag_stride + slot;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         const uint32_t got = __hip_atomic_load(in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((int32_t)(got - x.seq) >= 0) break;
+        if ((int32_t)((got & ~0xFFu) - want) >= 0)   // (a peer can be one exchange ahead)
+            return (got & ~0xFFu) == want && (got & 0xFFu) != ((uint32_t)x.mask & 0xFFu);
         if (__builtin_amdgcn_s_memrealtime() - t0 > x.timeout_ticks) {
             int32_t* st = reinterpret_cast<int32_t*>(static_cast<char*>(x.window[x.rank]) +
                                                      x.status_off);
             __hip_atomic_fetch_add(st, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
+            return true;
         }
         __builtin_amdgcn_s_sleep(2);
     }

@@ -32,7 +32,11 @@ constexpr int kLatentWaves = kLatentThreads / kWave;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 constexpr float kPoeEps = 1e-8f;
 constexpr int kHandoffSpins = 1 << 18;  // bounded wait of a consumer group (~0.3 s)
-constexpr int kHandoffWord = 63;        // word of a group's partial slab used as its flag
+constexpr int kStampWord = 80;          // (diagnostic build) unused words of a wave's LDS slot
+constexpr int kStampBase = 128;         // (diagnostic build) stamps sit behind the stats
+[[maybe_unused]] constexpr int kCtrStamp = MOPOE_NUM_COUNTERS;  // (diagnostic build) and behind the counters
+static_assert(kStampWord >= kNumPart && kStampWord + 1 < kStatStride, "stamp words are free");
+static_assert(kStampBase >= MOPOE_NUM_STATS, "stamps sit behind the stats");
 
 // Diagnostic build only (-DMOPOE_STAMPS, libmopoe_hip_stamps.so): thread 0 of
 // block 0 parks the low words of s_memrealtime [100 MHz] and s_memtime [shader
@@ -44,26 +48,26 @@ constexpr int kHandoffWord = 63;        // word of a group's partial slab used a
 #define STAMP(buf, i)                                                                  \
     do {                                                                               \
         if (stamp_blk && threadIdx.x == 0) {                                          \
-            stamp_lds[(i) * kStatStride + 48] =                                        \
+            stamp_lds[(i) * kStatStride + kStampWord] =                                        \
                 __uint_as_float((unsigned)__builtin_amdgcn_s_memrealtime());           \
-            stamp_lds[(i) * kStatStride + 49] =                                        \
+            stamp_lds[(i) * kStatStride + kStampWord + 1] =                                        \
                 __uint_as_float((unsigned)__builtin_amdgcn_s_memtime());               \
         }                                                                              \
     } while (0)
 #define STAMPW(buf, i, w)                                                              \
     do {                                                                               \
         if (stamp_blk && threadIdx.x == (w) * 64) {                                   \
-            stamp_lds[(i) * kStatStride + 48] =                                        \
+            stamp_lds[(i) * kStatStride + kStampWord] =                                        \
                 __uint_as_float((unsigned)__builtin_amdgcn_s_memrealtime());           \
-            stamp_lds[(i) * kStatStride + 49] =                                        \
+            stamp_lds[(i) * kStatStride + kStampWord + 1] =                                        \
                 __uint_as_float((unsigned)__builtin_amdgcn_s_memtime());               \
         }                                                                              \
     } while (0)
 #define STAMP_FLUSH(stats_ptr, n)                                                      \
     do {                                                                               \
         if (stamp_blk && threadIdx.x < 2 * (n))                                       \
-            (stats_ptr)[64 + threadIdx.x] =                                            \
-                stamp_lds[(threadIdx.x >> 1) * kStatStride + 48 + (threadIdx.x & 1)];  \
+            (stats_ptr)[kStampBase + threadIdx.x] =                                    \
+                stamp_lds[(threadIdx.x >> 1) * kStatStride + kStampWord + (threadIdx.x & 1)]; \
     } while (0)
 #else
 #define STAMP(buf, i) \
@@ -116,6 +120,8 @@ struct LinGroup {
     const float* b;        // (ncols) or nullptr
     float* Y;              // (n, ncols), row stride ldy
     int32_t K, ldx, ncols, ldy, relu;
+    int32_t xrows;         // rows of X: nothing past xrows * ldx floats is read (the range
+                           // check of the descriptor masks a 16-byte load over the tail)
     int32_t wslack;        // W stays readable 12 bytes past its end (a segment of the flat
                            // parameter buffer): rows whose length is not a multiple of 4
                            // are then read with 16-byte loads too
@@ -127,63 +133,135 @@ struct LinArgs {
     int32_t* counters;     // training step: bump [0], publish Adam coefficients
     int32_t publish;       // adam is valid: publish its step coefficients
     int32_t ksplit;        // 1, 2 or 4: K parts per column tile (set by launch_linear)
+    int32_t num_mods;      // modalities of the model (the Adam records of step_begin)
+    int32_t spins;         // fused launch: polls of a row group before it gives up
     mopoe_adam adam;
     LinGroup g[MOPOE_MAX_MODS];
 };
 
 // Adam scalars of step t, torch.optim.Adam (_single_tensor_adam) semantics:
-// python-double scalars applied to float32 tensors.  Computed once per step by
-// one thread of the step's first kernel and published next to the counters.
+// python-double scalars applied to float32 tensors.
 struct AdamCoef {
     float b2, one_m_b1, one_m_b2, step_size, bc2_sqrt, eps, pad;
 };
-constexpr int kCoefTag = 3;   // counters[3]: step the coefficients belong to
-constexpr int kCoefBase = 4;  // counters[4..]: AdamCoef as float bits
 
-DEV AdamCoef adam_coef(const mopoe_adam& ad, int t) {
+// torch keeps the step count PER PARAMETER and skips parameters whose .grad is None, so
+// every modality's parameters have their own count t_m (counters[MOPOE_CTR_ADAM_STEPS +
+// m]) and their own bias corrections 1 - beta1^t, sqrt(1 - beta2^t) -- two pow() in
+// double, ~1 us of one thread.  They are kept off every step's critical path: the ONE
+// block that ends a step's Adam kernel computes the records of the NEXT step, for all
+// modalities (the step of an absent one stays where it is), into slot (s + 1) & 1 of
+// counters[MOPOE_CTR_BIAS ..]; the readers of step s use slot s & 1, so nobody reads a
+// record while it is written.  A record is tagged with the step and the betas it was
+// computed for; the step's first kernel recomputes the ones that do not match (first
+// step ever, optimiser state loaded from outside, betas changed).
+struct BiasRec {
+    double bc1;      // 1 - beta1^t
+    float bc2_sqrt;  // sqrt(1 - beta2^t)
+    int32_t tag;     // global step the record belongs to
+};
+static_assert(sizeof(BiasRec) == 16, "four words per record");
+constexpr int kCtrBeta = 10;   // counters[10], [11]: bits of the betas the records were made for
+static_assert(MOPOE_CTR_BIAS + 2 * MOPOE_MAX_MODS * 4 <= MOPOE_NUM_COUNTERS, "records fit");
+
+DEV BiasRec* bias_rec(int32_t* counters, int s, int m) {
+    return reinterpret_cast<BiasRec*>(counters + MOPOE_CTR_BIAS) + ((s & 1) * MOPOE_MAX_MODS + m);
+}
+DEV BiasRec bias_of(const mopoe_adam& ad, int t, int tag) {
+    BiasRec r;
+    r.bc1 = 1.0 - pow((double)ad.beta1, (double)t);
+    r.bc2_sqrt = (float)sqrt(1.0 - pow((double)ad.beta2, (double)t));
+    r.tag = tag;
+    return r;
+}
+DEV bool betas_match(const int32_t* counters, const mopoe_adam& ad) {
+    return counters[kCtrBeta] == __builtin_bit_cast(int32_t, ad.beta1) &&
+           counters[kCtrBeta + 1] == __builtin_bit_cast(int32_t, ad.beta2);
+}
+DEV AdamCoef adam_coef_of(const mopoe_adam& ad, double bc1, float bc2_sqrt) {
     AdamCoef c;
-    const double b1 = (double)ad.beta1, b2 = (double)ad.beta2;
-    const double bc1 = 1.0 - pow(b1, (double)t);
-    const double bc2 = 1.0 - pow(b2, (double)t);
     c.b2 = ad.beta2;
-    c.one_m_b1 = (float)(1.0 - b1);
-    c.one_m_b2 = (float)(1.0 - b2);
+    c.one_m_b1 = (float)(1.0 - (double)ad.beta1);
+    c.one_m_b2 = (float)(1.0 - (double)ad.beta2);
     c.step_size = (float)((double)ad.lr / bc1);
-    c.bc2_sqrt = (float)sqrt(bc2);
+    c.bc2_sqrt = bc2_sqrt;
     c.eps = ad.eps;
     c.pad = 0.f;
     return c;
 }
 
-DEV AdamCoef adam_coef_load(const int32_t* counters, const mopoe_adam& ad) {
-    const int t = counters[0];
-    if (counters[kCoefTag] != t) return adam_coef(ad, t);  // not published
-    return *reinterpret_cast<const AdamCoef*>(counters + kCoefBase);
+// First kernel of a training step, ONE thread: the step number, and (when the step
+// applies Adam) records that are valid for it.
+DEV void step_begin(int32_t* counters, int num_mods, const mopoe_adam* ad) {
+    const int s = counters[MOPOE_CTR_STEPS_BEGUN] + 1;
+    counters[MOPOE_CTR_STEPS_BEGUN] = s;
+    if (!ad) return;
+    const bool same = betas_match(counters, *ad);
+    for (int m = 0; m < num_mods; ++m) {
+        BiasRec* r = bias_rec(counters, s, m);
+        if (!same || r->tag != s) *r = bias_of(*ad, counters[MOPOE_CTR_ADAM_STEPS + m] + 1, s);
+    }
+    counters[kCtrBeta] = __builtin_bit_cast(int32_t, ad->beta1);
+    counters[kCtrBeta + 1] = __builtin_bit_cast(int32_t, ad->beta2);
 }
 
-// The same in two halves, so that the loads go out beside a block's other operand
-// loads and the branch on their values sits where the data is first needed (a
-// branch right after the request would hold every later load back one round trip).
-struct AdamCoefRaw {
-    int t, tag;
-    AdamCoef c;
-};
-DEV AdamCoefRaw adam_coef_request(const int32_t* counters) {
-    AdamCoefRaw r;
-    r.t = __builtin_nontemporal_load(counters);
-    r.tag = __builtin_nontemporal_load(counters + kCoefTag);
-    const float* f = reinterpret_cast<const float*>(counters + kCoefBase);
-    r.c.b2 = __builtin_nontemporal_load(f + 0);
-    r.c.one_m_b1 = __builtin_nontemporal_load(f + 1);
-    r.c.one_m_b2 = __builtin_nontemporal_load(f + 2);
-    r.c.step_size = __builtin_nontemporal_load(f + 3);
-    r.c.bc2_sqrt = __builtin_nontemporal_load(f + 4);
-    r.c.eps = __builtin_nontemporal_load(f + 5);
-    r.c.pad = 0.f;
-    return r;
+// Last block of the kernel that applied (or, on an invalid step, withheld) the Adam
+// update of step s, threads m < num_mods: advance the counts of the modalities that
+// were updated, write every modality's record of step s + 1.
+DEV void step_end(int32_t* counters, int s, int m, int num_mods, int present_mask, bool applied,
+                  const mopoe_adam& ad) {
+    if (m >= num_mods) return;
+    int t = counters[MOPOE_CTR_ADAM_STEPS + m];
+    if (applied && ((present_mask >> m) & 1)) counters[MOPOE_CTR_ADAM_STEPS + m] = ++t;
+    *bias_rec(counters, s + 1, m) = bias_of(ad, t + 1, s + 1);
+    if (m == 0) {
+        counters[kCtrBeta] = __builtin_bit_cast(int32_t, ad.beta1);
+        counters[kCtrBeta + 1] = __builtin_bit_cast(int32_t, ad.beta2);
+    }
 }
-DEV AdamCoef adam_coef_resolve(const AdamCoefRaw& r, const mopoe_adam& ad) {
-    return r.tag == r.t ? r.c : adam_coef(ad, r.t);
+
+// A block's coefficients for modality m: both parity slots, the step number and the
+// invalid word are requested together, early, next to the block's other operands; the
+// selection sits where the values are first needed (a branch right after the request
+// would hold every later load back one round trip).
+struct AdamCoefRaw {
+    int s, invalid, b1, b2;
+    BiasRec r[2];
+};
+DEV AdamCoefRaw adam_coef_request(const int32_t* counters, int m) {
+    AdamCoefRaw q;
+    q.s = __builtin_nontemporal_load(counters + MOPOE_CTR_STEPS_BEGUN);
+    q.invalid = __builtin_nontemporal_load(counters + MOPOE_CTR_INVALID);
+    q.b1 = __builtin_nontemporal_load(counters + kCtrBeta);
+    q.b2 = __builtin_nontemporal_load(counters + kCtrBeta + 1);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int32_t* w = counters + MOPOE_CTR_BIAS + (k * MOPOE_MAX_MODS + m) * 4;
+        const uint32_t lo = (uint32_t)__builtin_nontemporal_load(w);
+        const uint32_t hi = (uint32_t)__builtin_nontemporal_load(w + 1);
+        q.r[k].bc1 = __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+        q.r[k].bc2_sqrt = __builtin_bit_cast(float, __builtin_nontemporal_load(w + 2));
+        q.r[k].tag = __builtin_nontemporal_load(w + 3);
+    }
+    return q;
+}
+// false: the step must not be applied (MOPOE_CTR_INVALID is up, or there is no record
+// for this step -- which the step's first kernel rules out)
+DEV bool adam_coef_resolve(const AdamCoefRaw& q, const mopoe_adam& ad, AdamCoef& c) {
+    const BiasRec r = (q.s & 1) ? q.r[1] : q.r[0];
+    c = adam_coef_of(ad, r.bc1, r.bc2_sqrt);
+    return q.invalid == 0 && r.tag == q.s && q.b1 == __builtin_bit_cast(int32_t, ad.beta1) &&
+           q.b2 == __builtin_bit_cast(int32_t, ad.beta2);
+}
+// The Adam kernels that run on their own (k_adam, k_xgmi), one thread per block: the
+// record if it is there, else the same numbers from the count (nobody writes the counts
+// before the kernel's last block has seen every other block finish).
+DEV AdamCoef adam_coef_load(const int32_t* counters, int m, const mopoe_adam& ad) {
+    const int s = counters[MOPOE_CTR_STEPS_BEGUN];
+    const BiasRec* r = bias_rec(const_cast<int32_t*>(counters), s, m);
+    if (r->tag == s && betas_match(counters, ad)) return adam_coef_of(ad, r->bc1, r->bc2_sqrt);
+    const BiasRec f = bias_of(ad, counters[MOPOE_CTR_ADAM_STEPS + m] + 1, s);
+    return adam_coef_of(ad, f.bc1, f.bc2_sqrt);
 }
 
 DEV void adam_update(const AdamCoef& c, float g, float p, float m, float v, float* po,
@@ -233,7 +311,7 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
     const int n0 = blockIdx.y * kRows;
     const int tile = wave / KS, part = wave % KS;
     const int j0 = (blockIdx.x * (4 / KS) + tile) * 16;
-    const rsrc_t xr = make_rsrc_max(g.X);
+    const rsrc_t xr = make_rsrc(g.X, (size_t)g.xrows * g.ldx * sizeof(float));
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     for (int kc0 = 0; kc0 < K; kc0 += kEncKChunk) {
         const int Kc = min(kEncKChunk, K - kc0);
@@ -281,7 +359,7 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
             }
         }
         __syncthreads();
-        GSTAMP(a.counters, 14, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
+        GSTAMP(a.counters, kCtrStamp + 14, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
         for (int i0 = 0; 16 * (part + KS * i0) < kend; i0 += CH) {
             f32x4 bn[CH];
             const bool more = 16 * (part + KS * (i0 + CH)) < kend;  // wave-uniform
@@ -309,7 +387,7 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
         }
     }
     acc += acc2;
-    GSTAMP(a.counters, 15, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
+    GSTAMP(a.counters, kCtrStamp + 15, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
     if (KS > 1) {  // parts 1.. hand their partial tiles over through LDS (behind the x tile)
         float* red = lds + kRows * (round_up(min(K, kEncKChunk), 16) + 4);
         if (part > 0) *reinterpret_cast<f32x4*>(red + ((wave - 1) * kWave + lane) * 4) = acc;
@@ -340,14 +418,9 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
     // wave id as a provably wave-uniform scalar (guide T20): everything derived
     // from it stays in SGPRs and buffer descriptors need no waterfall loop
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    GSTAMP(a.counters, 11, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
+    GSTAMP(a.counters, kCtrStamp + 11, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
     if (a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
-        const int t = a.counters[0] + 1;  // training step number (Adam, Philox)
-        a.counters[0] = t;
-        if (a.publish) {
-            *reinterpret_cast<AdamCoef*>(a.counters + kCoefBase) = adam_coef(a.adam, t);
-            a.counters[kCoefTag] = t;
-        }
+        step_begin(a.counters, a.num_mods, a.publish ? &a.adam : nullptr);
     }
     const LinGroup& g = a.g[blockIdx.z];
     const int ks = a.ksplit;
@@ -359,7 +432,7 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
         if (tid < kRows) rowsel[tid] = g.rows[min((int)blockIdx.y * kRows + tid, a.n - 1)];
         __syncthreads();
     }
-    GSTAMP(a.counters, 13, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
+    GSTAMP(a.counters, kCtrStamp + 13, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
     const int* rs = gather ? rowsel : nullptr;
     if (ks == 4)
         linear_tile<4>(a, g, lds, rs, tid, lane, wave);
@@ -367,7 +440,7 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
         linear_tile<2>(a, g, lds, rs, tid, lane, wave);
     else
         linear_tile<1>(a, g, lds, rs, tid, lane, wave);
-    GSTAMP(a.counters, 12, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
+    GSTAMP(a.counters, kCtrStamp + 12, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -393,12 +466,7 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a_by_value) {
     const int c16 = lane & 15, q = lane >> 4;
     const int N = a.n;
     if (a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
-        const int t = a.counters[0] + 1;  // training step number (Adam, Philox)
-        a.counters[0] = t;
-        if (a.publish) {
-            *reinterpret_cast<AdamCoef*>(a.counters + kCoefBase) = adam_coef(a.adam, t);
-            a.counters[kCoefTag] = t;
-        }
+        step_begin(a.counters, a.num_mods, a.publish ? &a.adam : nullptr);
     }
     const LinGroup& g = a.g[blockIdx.z];
     const int j0 = blockIdx.x * kBigCols, n0 = blockIdx.y * kBigRows;
@@ -409,7 +477,7 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a_by_value) {
         rowsel[tid] = g.rows ? g.rows[gn] : gn;
     }
     __syncthreads();
-    const rsrc_t xr = make_rsrc_max(g.X);
+    const rsrc_t xr = make_rsrc(g.X, (size_t)g.xrows * g.ldx * sizeof(float));
     const rsrc_t wr = make_rsrc(g.W, (size_t)g.ncols * K * sizeof(float));
     const bool vec = K % 4 == 0;
     // staging: thread -> 4 float4 of the x chunk and 4 of the W chunk (rows r0 + 16 i)
@@ -523,7 +591,7 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
         if (tid < kRows) rowsel[tid] = g.rows[min(n0 + tid, N - 1)];
         __syncthreads();
     }
-    const rsrc_t xr = make_rsrc_max(g.X);
+    const rsrc_t xr = make_rsrc(g.X, (size_t)g.xrows * g.ldx * sizeof(float));
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     for (int kc0 = 0; kc0 < K; kc0 += kEncKChunk) {
         const int Kc = min(kEncKChunk, K - kc0);
@@ -623,7 +691,7 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
     }
     // (diagnostic build: when each producer of row tile 0 has issued its stores;
     //  tools/fused_handoff_timeline.py -- needs a counters buffer of 32 words)
-    GSTAMP(a.counters, 16 + slot * 4 + cg, a.counters && rt == 0 && tid == 0);
+    GSTAMP(a.counters, kCtrStamp + 16 + slot * 4 + cg, a.counters && rt == 0 && tid == 0);
     // hand-off: every storing wave drains its stores, then ONE lane signals
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -641,14 +709,8 @@ __global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value
         const int tid = threadIdx.x, lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const LinArgs& a = f.la;
-        if (a.counters && b == 0 && tid == 0) {
-            const int t = a.counters[0] + 1;  // training step number (Adam, Philox)
-            a.counters[0] = t;
-            if (a.publish) {
-                *reinterpret_cast<AdamCoef*>(a.counters + kCoefBase) = adam_coef(a.adam, t);
-                a.counters[kCoefTag] = t;
-            }
-        }
+        // (the step number and the Adam records are looked after by row group 0 while it
+        //  waits for its producers: step_begin has no business on a producer's path)
         if (f.ks == 4) {
             const int cg = b & 3, rt = (b >> 2) % f.row_tiles, z = (b >> 2) / f.row_tiles;
             int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * stride + kHandoffWord);
@@ -662,15 +724,17 @@ __global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value
     }
     const int grp = b - f.nlin;
     int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)grp * stride + kHandoffWord);
-    latent_body<true, LEAN>(f.ka, lds, grp, flag, f.ks * f.la.ngroups);
+    latent_body<true, LEAN>(f.ka, lds, grp, flag, f.ks * f.la.ngroups, &f.la);
 }
 
 // Scalars of the step from the row tiles' partial sums, in a fixed order
-// (run_epochs.py:89-128, mm_div.py:92-111, kl_div.py:7-14).  One block of 256
-// threads; one thread per scalar -- a single thread walking the descriptor
-// arrays pays one scalar-memory round trip per element and took ~11 us.
-template <int SLICES>  // = block size / 64
+// (run_epochs.py:89-128, mm_div.py:92-111, kl_div.py:7-14; utils/TBLogger.py:26-37 for
+// the latent means).  One block; one thread per scalar -- a single thread walking the
+// descriptor arrays pays one scalar-memory round trip per element and took ~11 us.
+template <int THREADS>  // block size
 DEV void finalize_stats(const KArgs& a, int tid) {
+    constexpr int SLICES = THREADS / kStatStride;
+    static_assert(SLICES >= 1, "a thread per partial index");
     __shared__ float slab[SLICES][kStatStride];
     __shared__ float kld[kStatStride];      // scalar values, by partial index
     __shared__ float contrib[kStatStride];  // their share of total_loss
@@ -679,10 +743,11 @@ DEV void finalize_stats(const KArgs& a, int tid) {
     const mopoe_step& st = a.st;
     const int tiles = cdiv(st.n, a.lds.rows);
     const int stride = a.lds.part_stride;
-    {   // partial index p = tid % 64, tile slice = tid / 64; slices summed in order.
-        // Four interleaved accumulators keep four loads in flight per thread (a
-        // 50,000-row forward has 3125 row groups to add up).
-        const int p = tid & 63, sl = tid >> 6;
+    if (tid < SLICES * kStatStride) {
+        // partial index p = tid % kStatStride, tile slice = tid / kStatStride; slices
+        // summed in order.  Four interleaved accumulators keep four loads in flight per
+        // thread (a 50,000-row forward has 3125 row groups to add up).
+        const int p = tid % kStatStride, sl = tid / kStatStride;
         const int per = cdiv(tiles, SLICES);
         const int t1 = min((sl + 1) * per, tiles);
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -721,13 +786,19 @@ DEV void finalize_stats(const KArgs& a, int tid) {
                 v = -0.5f * sum / fn;
                 c = st.style_kl_coef[m] * v;
             }
-        } else {                                        // NLL of decoder job j
+        } else if (tid < kPartMean) {                   // NLL of decoder job j
             const int j = tid - kPartNll;
             out = MOPOE_STAT_NLL + j;
             if (j < st.num_jobs) {
                 v = sum / fn;
                 c = st.job_nll_coef[j] * v;
             }
+        } else {                                        // mean of an encoder output
+            const int m = (tid - kPartMean) >> 2, k = (tid - kPartMean) & 3;
+            out = MOPOE_STAT_LATENT_MEAN + (tid - kPartMean);
+            const int cols = k < 2 ? a.mdl.style_dim[m < a.mdl.num_mods ? m : 0] : a.mdl.class_dim;
+            if (m < a.mdl.num_mods && ((st.present_mask >> m) & 1) && cols > 0)
+                v = sum / (fn * (float)cols);           // (no share of the loss)
         }
         kld[tid] = v;
         contrib[tid] = c;
@@ -741,7 +812,7 @@ DEV void finalize_stats(const KArgs& a, int tid) {
     if (tid == 0) {
         float total = 0.f, jd = 0.f;
 #pragma unroll
-        for (int i = 0; i < kNumPart; ++i) total += contrib[i];
+        for (int i = 0; i < kPartMean; ++i) total += contrib[i];
 #pragma unroll
         for (int k = 0; k < MOPOE_MAX_SUBSETS; ++k) jd += jdc[k];
         buf.stats[MOPOE_STAT_TOTAL_LOSS] = total;
@@ -771,6 +842,8 @@ struct WJob {
     int32_t ldg, gcols, ldx, xcols, R;
     int32_t off_w, off_b;
     int32_t tiles_j, tile_begin;
+    int32_t mod;           // modality of the parameters (its own Adam step count)
+    int32_t xtotal;        // rows of X (the descriptor covers exactly xtotal * ldx floats)
 };
 
 struct WArgs {
@@ -873,7 +946,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
     const bool fuse = w.fuse_adam != 0;
     const bool stamp_blk = b == 20 && tid == 0;  // a W1 block of the large modality
     (void)stamp_blk;
-    GSTAMP(buf.stats, 64 + 40, stamp_blk);
+    GSTAMP(buf.stats, kStampBase + 40, stamp_blk);
 
     if (b < w.total_tiles) {
         // job of this block: compares against one contiguous table (a scan over
@@ -903,7 +976,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         float bp = 0.f, bm = 0.f, bv = 0.f;
         AdamCoefRaw acr;
         if (fuse) {
-            acr = adam_coef_request(buf.counters);
+            acr = adam_coef_request(buf.counters, job.mod);
             const uint32_t o = guard((uint32_t)widx * 4u, nvalid > 0);
             pp = ldg4(rp, o);
             pm = ldg4(rm, o);
@@ -914,11 +987,11 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
             bv = ldg(rv, ob);
         }
 
-        GSTAMP(buf.stats, 64 + 41, stamp_blk);
+        GSTAMP(buf.stats, kStampBase + 41, stamp_blk);
         const int rq = round_up(cdiv(R, kWgWaves), 4);
         const int rbeg = wave * rq, rend = min(rbeg + rq, R);
         const rsrc_t gr = make_rsrc(job.G, (size_t)R * job.ldg * sizeof(float));
-        const rsrc_t xr = make_rsrc_max(job.X);
+        const rsrc_t xr = make_rsrc(job.X, (size_t)job.xtotal * job.ldx * sizeof(float));
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         f32x4 acc[2][2] = {{z4, z4}, {z4, z4}};
         // rounds of 64 batch rows (32 loads in flight), or of 32 when a wave's share is
@@ -939,7 +1012,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
                 wgrad_rows<false, 16>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
                                       rbeg, rend, lane, acc);
         }
-        GSTAMP(buf.stats, 64 + 42, stamp_blk);
+        GSTAMP(buf.stats, kStampBase + 42, stamp_blk);
         // this wave's partial block -> LDS as [i][j]
         {
             const int c = lane & 15, q = lane >> 4;
@@ -960,9 +1033,12 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
 #pragma unroll
         for (int k = 1; k < kWgWaves; ++k)  // fixed order
             g += *reinterpret_cast<const f32x4*>(&blk[k][li * kWgLd + lj]);
-        GSTAMP(buf.stats, 64 + 43, stamp_blk);
+        GSTAMP(buf.stats, kStampBase + 43, stamp_blk);
+        // (an invalid step -- a hand-off or an exchange that timed out -- leaves parameters
+        //  and moments alone: run_epochs.py:180-182 never applies half a step)
         AdamCoef ac;
-        if (fuse) ac = adam_coef_resolve(acr, w.adam);
+        bool apply = false;
+        if (fuse) apply = adam_coef_resolve(acr, w.adam, ac);
         const int eb = xcols - ej;   // has_b: the bias column inside this thread's four
         float gb = eb == 0 ? g[0] : eb == 1 ? g[1] : eb == 2 ? g[2] : g[3];
         float gscale = 1.f;
@@ -990,8 +1066,14 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // pushes have landed
             __syncthreads();
-            xg_signal_and_wait(x, tid, b);
-            __syncthreads();
+            // (a failed exchange -- a wait out of budget, a peer with other modalities --
+            //  withholds this block's update and raises the sticky invalid word)
+            if (__syncthreads_or(xg_signal_and_wait(x, tid, b))) {
+                apply = false;
+                if (tid == 0)
+                    __hip_atomic_fetch_add(buf.counters + MOPOE_CTR_INVALID, 1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
             f32x4 in[MOPOE_MAX_RANKS];
             float inb[MOPOE_MAX_RANKS];
 #pragma unroll
@@ -1022,7 +1104,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         }
         if (nvalid > 0) {
             f32x4 np = pp, nm = pm, nv = pv;
-            if (fuse) {
+            if (apply) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float po, mo, vo;
@@ -1036,7 +1118,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
             if (nvalid >= 4) {
                 const rsrc_t rg = make_rsrc(buf.grads, pbytes);
                 stg4_wt(rg, (uint32_t)widx * 4u, g);
-                if (fuse) {
+                if (apply) {
                     stg4_wt(rp, (uint32_t)widx * 4u, np);
                     stg4_wt(rm, (uint32_t)widx * 4u, nm);
                     stg4_wt(rv, (uint32_t)widx * 4u, nv);
@@ -1044,7 +1126,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
             } else {
                 for (int e = 0; e < nvalid; ++e) {
                     buf.grads[widx + e] = g[e];
-                    if (fuse) {
+                    if (apply) {
                         buf.params[widx + e] = np[e];
                         buf.exp_avg[widx + e] = nm[e];
                         buf.exp_avg_sq[widx + e] = nv[e];
@@ -1054,18 +1136,16 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         }
         if (has_b) {
             buf.grads[bidx] = gb;
-            if (fuse)
+            if (apply)
                 adam_update(ac, XG ? __fmul_rn(gb, gscale) : gb, bp, bm, bv, buf.params + bidx,
                             buf.exp_avg + bidx, buf.exp_avg_sq + bidx);
         }
-        GSTAMP(buf.stats, 64 + 44, stamp_blk);
+        GSTAMP(buf.stats, kStampBase + 44, stamp_blk);
         return;
     }
-    AdamCoef ac;
-    if (fuse) ac = adam_coef_load(buf.counters, w.adam);
     const int lb = b - w.total_tiles;
     if (lb < w.lvo_blocks) {
-        GSTAMP(buf.stats, 64 + 62, lb == w.lvo_blocks - 1 && tid == 0);
+        GSTAMP(buf.stats, kStampBase + 62, lb == w.lvo_blocks - 1 && tid == 0);
         const int tiles = cdiv(a.st.n, a.lds.rows);
         const int stride = a.lds.part_stride;
         // d loss / d decoders.<m>.logvar: sum of the row groups' partials.  A block
@@ -1073,6 +1153,9 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         // loads in flight per thread) and are added in fixed order through LDS.
         int m = 0;
         while (lb >= w.lvo_block_begin[m + 1]) ++m;
+        AdamCoef ac;
+        bool apply = false;
+        if (fuse) apply = adam_coef_resolve(adam_coef_request(buf.counters, m), w.adam, ac);
         const int col = (lb - w.lvo_block_begin[m]) * 64 + lane;
         const bool on = col < a.mdl.input_dim[m];
         float g = 0.f;
@@ -1119,7 +1202,12 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
                         st4_sys(rr, o, g);
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    xg_signal_and_wait(x, lane, b);
+                    if (__any(xg_signal_and_wait(x, lane, b))) {
+                        apply = false;
+                        if (lane == 0)
+                            __hip_atomic_fetch_add(buf.counters + MOPOE_CTR_INVALID, 1,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     float in[MOPOE_MAX_RANKS];
 #pragma unroll
                     for (int r = 0; r < MOPOE_MAX_RANKS; ++r) {
@@ -1141,7 +1229,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
             if (on) {
                 if (a.mdl.learn_output_scale) {
                     buf.grads[idx] = g;
-                    if (fuse)
+                    if (apply)
                         adam_update(ac, XG ? __fmul_rn(g, gscale) : g, buf.params[idx],
                                     buf.exp_avg[idx], buf.exp_avg_sq[idx], buf.params + idx,
                                     buf.exp_avg + idx, buf.exp_avg_sq + idx);
@@ -1150,21 +1238,38 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
                 }
             }
         }
-        GSTAMP(buf.stats, 64 + 63, lb == w.lvo_blocks - 1 && tid == 0);
+        GSTAMP(buf.stats, kStampBase + 63, lb == w.lvo_blocks - 1 && tid == 0);
         return;
     }
     // last block: scalars of the step (run_epochs.py:89-128) + step counter
-    GSTAMP(buf.stats, 64 + 60, tid == 0);
-    finalize_stats<kWgWaves>(a, tid);
-    GSTAMP(buf.stats, 64 + 61, tid == 0);
-    if (tid == 0 && a.st.backward) buf.counters[1] += 1;
+    GSTAMP(buf.stats, kStampBase + 60, tid == 0);
+    finalize_stats<kWgWaves * 64>(a, tid);
+    GSTAMP(buf.stats, kStampBase + 61, tid == 0);
+    // control words behind the last segment of the gradient buffer: which modalities this
+    // rank's batch held (they ride through the ranks' all-reduce; mopoe_adam_step checks)
+    if (tid < MOPOE_MAX_MODS)
+        buf.grads[a.mdl.off_ctrl + tid] = (a.st.present_mask >> tid) & 1 ? 1.f : 0.f;
+    if (a.st.backward) {
+        const int s = buf.counters[MOPOE_CTR_STEPS_BEGUN];
+        const int invalid = buf.counters[MOPOE_CTR_INVALID];
+        // (the GEMM blocks read slot s & 1 and never the counts: nothing they read changes)
+        if (fuse) step_end(buf.counters, s, tid, a.mdl.num_mods, a.st.present_mask, invalid == 0, w.adam);
+        if (tid == 0) {
+            const int done = buf.counters[MOPOE_CTR_STEPS_DONE] + 1;
+            buf.counters[MOPOE_CTR_STEPS_DONE] = done;
+            if (buf.status_host) {
+                buf.status_host[0] = done;
+                buf.status_host[1] = invalid;
+            }
+        }
+    }
 }
 
 // forward-only finalisation of the scalars
 __global__ __launch_bounds__(1024) void k_finalize(const KArgs a_by_value) {
     (void)a_by_value;  // read in place (see k_latent)
     const KArgs& a = *(const KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    finalize_stats<16>(a, threadIdx.x);
+    finalize_stats<1024>(a, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1175,25 +1280,65 @@ struct AdamSegs {
     int32_t nseg;
     int32_t begin[2 * MOPOE_MAX_MODS];
     int32_t end[2 * MOPOE_MAX_MODS];
-    float grad_scale;
+    int32_t seg_mod[2 * MOPOE_MAX_MODS];   // modality of the segment (its Adam step count)
+    int32_t num_mods, present_mask;
+    int32_t world;        // ranks whose gradients were summed into buf.grads (1: none)
+    int32_t off_ctrl;     // control words of the gradient buffer (mopoe_model.off_ctrl)
+    float grad_scale;     // 1 / world
     mopoe_adam adam;
-    int32_t host_coef;   // coef below was computed on the host for a known step
-    AdamCoef coef;
 };
+
+// Whether the step may be applied: no sticky invalid word, and (data-parallel) every
+// rank's batch held this rank's modalities -- control word m of the summed gradient
+// buffer is then `world` for a present modality and 0 for an absent one.
+DEV bool adam_step_valid(const mopoe_buffers& buf, const AdamSegs& s, const float* ctrl) {
+    bool ok = buf.counters[MOPOE_CTR_INVALID] == 0;
+    if (s.world > 1)
+        for (int m = 0; m < s.num_mods; ++m)
+            ok &= ctrl[m] == ((s.present_mask >> m) & 1 ? (float)s.world : 0.f);
+    return ok;
+}
+// The block that finishes last ends the step: counts, next step's records, the sticky
+// word when the ranks disagreed.  (Every other block has read what it needs before it
+// takes its ticket.)
+DEV void adam_kernel_end(const mopoe_buffers& buf, const AdamSegs& s, bool valid, int total_blocks,
+                         int tid) {
+    __shared__ int last;
+    __syncthreads();
+    if (tid == 0)
+        last = __hip_atomic_fetch_add(buf.counters + MOPOE_CTR_TICKET, 1, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT) == total_blocks - 1;
+    __syncthreads();
+    if (!last) return;
+    const int step = buf.counters[MOPOE_CTR_STEPS_BEGUN];
+    step_end(buf.counters, step, tid, s.num_mods, s.present_mask, valid, s.adam);
+    if (tid == 0) {
+        buf.counters[MOPOE_CTR_TICKET] = 0;
+        if (!valid && buf.counters[MOPOE_CTR_INVALID] == 0) buf.counters[MOPOE_CTR_INVALID] = 1;
+        if (buf.status_host) buf.status_host[1] = buf.counters[MOPOE_CTR_INVALID];
+    }
+}
 
 __global__ __launch_bounds__(256) void k_adam(const mopoe_buffers buf, const AdamSegs s) {
     __shared__ AdamCoef sc;
-    if (threadIdx.x == 0) sc = s.host_coef ? s.coef : adam_coef_load(buf.counters, s.adam);
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        sc = adam_coef_load(buf.counters, s.seg_mod[blockIdx.y], s.adam);
+        ok = adam_step_valid(buf, s, buf.grads + s.off_ctrl);
+    }
     __syncthreads();
     const AdamCoef ac = sc;
+    const bool valid = ok != 0;
     const int beg = s.begin[blockIdx.y], end = s.end[blockIdx.y];
-    for (int i = beg + blockIdx.x * blockDim.x + threadIdx.x; i < end;
-         i += gridDim.x * blockDim.x) {
-        // a multiply of its own (never contracted into the update), as in k_xgmi
-        const float g = __fmul_rn(buf.grads[i], s.grad_scale);
-        adam_update(ac, g, buf.params[i], buf.exp_avg[i], buf.exp_avg_sq[i], buf.params + i,
-                    buf.exp_avg + i, buf.exp_avg_sq + i);
-    }
+    if (valid)
+        for (int i = beg + blockIdx.x * blockDim.x + threadIdx.x; i < end;
+             i += gridDim.x * blockDim.x) {
+            // a multiply of its own (never contracted into the update), as in k_xgmi
+            const float g = __fmul_rn(buf.grads[i], s.grad_scale);
+            adam_update(ac, g, buf.params[i], buf.exp_avg[i], buf.exp_avg_sq[i], buf.params + i,
+                        buf.exp_avg + i, buf.exp_avg_sq + i);
+        }
+    adam_kernel_end(buf, s, valid, gridDim.x * gridDim.y, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1395,6 +1540,13 @@ int validate(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* 
         if (!((st->present_mask >> m) & 1)) continue;
         if (!buf->x[m] || !buf->hidden[m] || !buf->heads[m] || !buf->z[m] || !buf->loc[m])
             return fail(MOPOE_ERR_ARG, "null forward buffer%s");
+        // x[m] is read through a descriptor of exactly x_rows[m] * d_m floats
+        if (buf->x_rows[m] < 0 || (buf->row_index[m] && buf->x_rows[m] < 1))
+            return fail(MOPOE_ERR_ARG, "x_rows[m] (rows of x[m]) is required with row_index[m]%s");
+        if (!buf->row_index[m] && buf->x_rows[m] != 0 && buf->x_rows[m] < st->n)
+            return fail(MOPOE_ERR_ARG, "x[m] has fewer rows than the batch%s");
+        if ((long long)(buf->x_rows[m] ? buf->x_rows[m] : st->n) * mdl->input_dim[m] * 4 >= (1ll << 31))
+            return fail(MOPOE_ERR_ARG, "x[m] too large for 32-bit row offsets%s");
         if (train && (!buf->g_xhat[m] || !buf->g_heads[m] || !buf->g_pre[m]))
             return fail(MOPOE_ERR_ARG, "null backward buffer%s");
         // the kernels address every per-row tensor with 32-bit byte offsets whose top bit
@@ -1414,6 +1566,13 @@ int validate(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* 
     if (reinterpret_cast<uintptr_t>(buf->params) & 255)
         return fail(MOPOE_ERR_ARG, "params must be 256-byte aligned%s");
     return 0;
+}
+
+// the kernels' view of the caller's buffers: x_rows filled in for identity batches
+void bind_buffers(KArgs& ka, const mopoe_buffers& buf) {
+    ka.buf = buf;
+    for (int m = 0; m < MOPOE_MAX_MODS; ++m)
+        if (!ka.buf.x_rows[m]) ka.buf.x_rows[m] = ka.st.n;
 }
 
 int latent_lds_bytes(const mopoe_model& mdl, const mopoe_step& st) {
@@ -1450,6 +1609,13 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s) 
 // MOPOE_FUSE_BLOCKS caps the grid the fused launch is used for.  Read per call (two
 // getenv), so a test can compare the two forms inside one process.
 static bool no_fuse() { return getenv("MOPOE_NO_FUSE") != nullptr; }
+// MOPOE_TEST_HANDOFF_SPINS: a test knob -- with 1 a row group gives up at its first poll, which
+// is how tests/test_hip_invalid.py drives the "step could not be completed" path.
+static int handoff_spins() {
+    const char* v = getenv("MOPOE_TEST_HANDOFF_SPINS");
+    const int n = v ? atoi(v) : kHandoffSpins;
+    return n > 0 ? n : kHandoffSpins;
+}
 static int fuse_blocks() {
     const char* v = getenv("MOPOE_FUSE_BLOCKS");
     return v ? atoi(v) : 256;
@@ -1462,6 +1628,8 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     la.n = ka.st.n;
     la.counters = ka.st.backward ? ka.buf.counters : nullptr;
     la.publish = adam != nullptr;
+    la.num_mods = mdl.num_mods;
+    la.spins = handoff_spins();
     if (adam) la.adam = *adam;
     int maxd = 1;
     for (int m = 0; m < mdl.num_mods; ++m) {
@@ -1476,6 +1644,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         g.Y = ka.buf.hidden[m];
         g.K = d;
         g.ldx = d;
+        g.xrows = ka.buf.x_rows[m];
         g.ncols = kHid;
         g.ldy = kHid;
         g.relu = 1;
@@ -1555,11 +1724,11 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w, const XgPeer
         const int d = mdl.input_dim[m], nh = heads_dim(mdl, m), zd = z_dim(mdl, m);
         WJob jobs[3] = {
             {ka.buf.g_pre[m], ka.buf.x[m], ka.buf.row_index[m], kHid, kHid, d, d, st.n,
-             mdl.off_w1[m], mdl.off_b1[m], 0, 0},
+             mdl.off_w1[m], mdl.off_b1[m], 0, 0, m, ka.buf.x_rows[m]},
             {ka.buf.g_heads[m], ka.buf.hidden[m], nullptr, nh, nh, kHid, kHid, st.n,
-             mdl.off_wh[m], mdl.off_bh[m], 0, 0},
+             mdl.off_wh[m], mdl.off_bh[m], 0, 0, m, st.n},
             {ka.buf.g_xhat[m], ka.buf.z[m], nullptr, d, d, ldz_glb(mdl, m), zd,
-             njobs_m * st.n, mdl.off_wd[m], mdl.off_bd[m], 0, 0},
+             njobs_m * st.n, mdl.off_wd[m], mdl.off_bd[m], 0, 0, m, njobs_m * st.n},
         };
         for (int k = 0; k < 3; ++k) {
             WJob& jb = jobs[k];
@@ -1584,30 +1753,26 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w, const XgPeer
 }
 
 int build_adam_segs(const mopoe_model& mdl, int32_t present_mask, const mopoe_adam& adam,
-                    float grad_scale, int32_t step, AdamSegs& sg) {
+                    int32_t world, AdamSegs& sg) {
     memset(&sg, 0, sizeof(sg));
+    if (world < 1) return fail(MOPOE_ERR_ARG, "world must be >= 1%s");
     for (int m = 0; m < mdl.num_mods; ++m) {
         if (!((present_mask >> m) & 1)) continue;
+        sg.seg_mod[sg.nseg] = m;
         sg.begin[sg.nseg] = mdl.off_w1[m];
         sg.end[sg.nseg++] = mdl.off_bh[m] + heads_dim(mdl, m);
+        sg.seg_mod[sg.nseg] = m;
         sg.begin[sg.nseg] = mdl.off_wd[m];
         sg.end[sg.nseg++] = mdl.learn_output_scale ? mdl.off_lvo[m] + mdl.input_dim[m]
                                                    : mdl.off_bd[m] + mdl.input_dim[m];
     }
     if (sg.nseg == 0) return fail(MOPOE_ERR_ARG, "empty present_mask%s");
-    sg.grad_scale = grad_scale;
+    sg.num_mods = mdl.num_mods;
+    sg.present_mask = present_mask;
+    sg.world = world;
+    sg.off_ctrl = mdl.off_ctrl;
+    sg.grad_scale = 1.0f / (float)world;
     sg.adam = adam;
-    if (step > 0) {  // same arithmetic as adam_coef(), done once on the host
-        const double b1 = (double)adam.beta1, b2 = (double)adam.beta2;
-        sg.host_coef = 1;
-        sg.coef.b2 = adam.beta2;
-        sg.coef.one_m_b1 = (float)(1.0 - b1);
-        sg.coef.one_m_b2 = (float)(1.0 - b2);
-        sg.coef.step_size = (float)((double)adam.lr / (1.0 - pow(b1, (double)step)));
-        sg.coef.bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)step));
-        sg.coef.eps = adam.eps;
-        sg.coef.pad = 0.f;
-    }
     return 0;
 }
 
@@ -1627,7 +1792,7 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
     KArgs ka;
     ka.mdl = *mdl;
     ka.st = *st;
-    ka.buf = *buf;
+    bind_buffers(ka, *buf);
     ka.st.backward = 1;
     ka.st.sample = 1;
     latent_lds_layout(ka.mdl, ka.st, kLatentWaves, ka.lds);
@@ -1641,7 +1806,10 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
     if (comm && (int)grid.x > comm_flag_stride(comm))   // one arrival flag per exchanging workgroup
         return fail(MOPOE_ERR_ARG, "more weight-gradient blocks than the communicator has flags%s");
     if (int rc = launch_forward_part(ka, adam, s)) return rc;
-    if (comm) comm_next(comm, w.xg);
+    if (comm) {
+        comm_next(comm, w.xg);
+        w.xg.mask = ka.st.present_mask;
+    }
     {
         ProfScope ps(MOPOE_KERNEL_WGRAD, s);
         if (ka.st.n > 512) {
@@ -1690,6 +1858,7 @@ int mopoe_model_layout(mopoe_model* mdl) {
         mdl->off_bd[m] = seg(d);
         mdl->off_lvo[m] = seg(d);
     }
+    mdl->off_ctrl = seg(64);   // control words of the gradient buffer (no parameters)
     mdl->num_floats = off;
     return 0;
 }
@@ -1729,6 +1898,8 @@ int mopoe_sizeof(int which) {
         case 4: return (int)offsetof(mopoe_step, job_eps_content);
         case 5: return (int)offsetof(mopoe_step, comp_w);
         case 6: return (int)offsetof(mopoe_buffers, partials);
+        case 8: return (int)offsetof(mopoe_buffers, status_host);
+        case 9: return (int)offsetof(mopoe_model, off_ctrl);
         case 7: return (int)offsetof(mopoe_model, num_floats);
         default: return -1;
     }
@@ -1751,7 +1922,7 @@ int mopoe_forward(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buff
     KArgs ka;
     ka.mdl = *mdl;
     ka.st = *st;
-    ka.buf = *buf;
+    bind_buffers(ka, *buf);
     ka.st.backward = 0;
     latent_lds_layout(ka.mdl, ka.st, kLatentWaves, ka.lds);
     latent_bind(ka.lds, ka.buf);
@@ -1770,12 +1941,12 @@ int mopoe_train_step(const mopoe_model* mdl, const mopoe_step* st, const mopoe_b
 }
 
 int mopoe_adam_step(const mopoe_model* mdl, int32_t present_mask, const mopoe_buffers* buf,
-                    const mopoe_adam* adam, float grad_scale, int32_t step, void* stream) {
+                    const mopoe_adam* adam, int32_t world, void* stream) {
     if (!mdl || !buf || !adam) return fail(MOPOE_ERR_ARG, "null descriptor%s");
     if (!buf->params || !buf->grads || !buf->exp_avg || !buf->exp_avg_sq || !buf->counters)
         return fail(MOPOE_ERR_ARG, "null optimiser buffer%s");
     AdamSegs sg;
-    if (int rc = build_adam_segs(*mdl, present_mask, *adam, grad_scale, step, sg)) return rc;
+    if (int rc = build_adam_segs(*mdl, present_mask, *adam, world, sg)) return rc;
     {
         ProfScope ps(MOPOE_KERNEL_ADAM, static_cast<hipStream_t>(stream));
         hipLaunchKernelGGL(k_adam, dim3(128, sg.nseg), dim3(256), 0,
@@ -1799,6 +1970,7 @@ int mopoe_linear(const float* x, int32_t n, int32_t k, const float* w, const flo
     g.Y = y;
     g.K = k;
     g.ldx = k;
+    g.xrows = n;
     g.ncols = ncols;
     g.ldy = ncols;
     g.relu = relu;
@@ -1924,16 +2096,14 @@ int mopoe_comm_allreduce(mopoe_comm* c, float* data, void* stream) {
 }
 
 int mopoe_comm_allreduce_adam(mopoe_comm* c, const mopoe_model* mdl, int32_t present_mask,
-                              const mopoe_buffers* buf, const mopoe_adam* adam, int32_t step,
-                              void* stream) {
+                              const mopoe_buffers* buf, const mopoe_adam* adam, void* stream) {
     if (!c || !mdl || !buf || !adam) return fail(MOPOE_ERR_ARG, "null descriptor%s");
     if (!buf->params || !buf->grads || !buf->exp_avg || !buf->exp_avg_sq || !buf->counters)
         return fail(MOPOE_ERR_ARG, "null optimiser buffer%s");
     if (mdl->num_floats != c->num_floats)
         return fail(MOPOE_ERR_ARG, "communicator was created for another buffer length%s");
     AdamSegs sg;
-    if (int rc = build_adam_segs(*mdl, present_mask, *adam, 1.0f / (float)c->world, step, sg))
-        return rc;
+    if (int rc = build_adam_segs(*mdl, present_mask, *adam, c->world, sg)) return rc;
     return comm_launch(c, buf->grads, buf, &sg, static_cast<hipStream_t>(stream));
 }
 

@@ -32,7 +32,7 @@ class Workspace:
         self.z = [torch.zeros(slots * n, spec.ldz(m), **f) for m in range(M)]
         self.loc = [torch.empty(slots * n, spec.input_dim[m], **f)
                     for m in range(M)]
-        self._stats_all = torch.zeros(64 + 128, **f)   # [64:] diagnostic stamps
+        self._stats_all = torch.zeros(L.STATS_ALLOC, **f)   # [128:] diagnostic stamps
         self.stats = self._stats_all[:L.NUM_STATS]
         self._f = f
         self._stride = L.lib.mopoe_partials_stride(spec.c_model)
@@ -65,13 +65,16 @@ class MoPoEEngine:
         self.grads = torch.zeros(P, **f)
         self.exp_avg = torch.zeros(P, **f)
         self.exp_avg_sq = torch.zeros(P, **f)
-        self.counters = torch.zeros(32, dtype=torch.int32, device=self.device)   # (16 + diagnostic stamps)
+        self.counters = torch.zeros(L.COUNTERS_ALLOC, dtype=torch.int32, device=self.device)
+        # pinned host mirror {steps done, invalid} the last kernel of every training step
+        # writes: an invalid step is noticed without synchronising (check_valid)
+        self.status_host = torch.zeros(4, dtype=torch.int32).pin_memory() \
+            if self._on_gpu else torch.zeros(4, dtype=torch.int32)
         self.device = self.params.device   # with its index: cheap `is it already there` tests
         self.views = spec.param_views(self.params)
         self.grad_views = spec.param_views(self.grads)
         self.seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1)
         self._calls = 0
-        self._host_step = 0     # mirror of counters[0] (training steps begun)
         self._ws = {}
         self._keep = None   # tensors the in-flight kernels read (x, eps)
         self.adam = L.Adam(spec.lr, spec.betas[0], spec.betas[1], spec.adam_eps)
@@ -100,7 +103,44 @@ class MoPoEEngine:
         return OrderedDict((k, v.detach().clone()) for k, v in self.views.items())
 
     def step_count(self):
-        return int(self.counters[0].item())
+        """Training steps begun (synchronises)."""
+        return int(self.counters[L.CTR_STEPS_BEGUN].item())
+
+    def adam_steps(self):
+        """Adam updates applied so far to each modality's parameters (torch keeps
+        state['step'] per parameter: a modality that sat out a batch is a step behind)."""
+        c = self.counters[L.CTR_ADAM_STEPS:L.CTR_ADAM_STEPS + self.spec.num_mods].tolist()
+        return OrderedDict(zip(self.spec.names, c))
+
+    # ------------------------------------------------------------ step validity
+    def check_valid(self, sync=False):
+        """Raises MopoeError when a training step could not be completed: a hand-off
+        inside the fused launch or a wait of the gradient exchange ran out of its
+        budget, or the ranks' batches held different modalities.  From that step on the
+        kernels apply NO Adam update (parameters and moments stay at the last complete
+        step, reference run_epochs.py:180-182 never applies half a step either) until
+        `recover()`.  Without `sync` this reads the pinned host mirror the kernels
+        write -- no device synchronisation, at most a step or two behind."""
+        if sync:
+            torch.cuda.synchronize(self.device)
+            bad = int(self.counters[L.CTR_INVALID].item())
+        else:
+            bad = int(self.status_host[1])
+        if bad:
+            raise L.MopoeError(
+                "a training step could not be completed (%d event(s): hand-off / "
+                "gradient-exchange time-out or ranks with different modalities); no "
+                "update has been applied since -- engine.recover() re-arms the step"
+                % bad)
+
+    def recover(self):
+        """Re-arm after an invalid step: clears the sticky word and the hand-off flags."""
+        torch.cuda.synchronize(self.device)
+        self.counters[L.CTR_INVALID] = 0
+        for ws in self._ws.values():
+            ws.partials.zero_()
+        self.status_host[1] = 0
+        torch.cuda.synchronize(self.device)
 
     # --------------------------------------------------------------- buffers
     def workspace(self, n, slots, backward, fresh=False):
@@ -127,9 +167,11 @@ class MoPoEEngine:
         b.exp_avg = L.ptr(self.exp_avg)
         b.exp_avg_sq = L.ptr(self.exp_avg_sq)
         b.counters = L.ptr(self.counters)
+        b.status_host = L.ptr(self.status_host)
         for m, name in enumerate(self.spec.names):
             if name in x:
                 b.x[m] = L.ptr(x[name])
+                b.x_rows[m] = x[name].shape[0]
                 if row_index is not None and row_index.get(name) is not None:
                     b.row_index[m] = L.ptr(row_index[name])
             b.hidden[m] = L.ptr(ws.hidden[m])
@@ -164,7 +206,7 @@ class MoPoEEngine:
         x = OrderedDict()
         n = None
         for name, v in batch.items():
-            t = L.rows_with_slack(v, self.device)   # (v itself when it already qualifies)
+            t = L.device_rows(v, self.device)   # (v itself when it already qualifies)
             m = self.spec.names.index(name)
             if t.dim() != 2 or t.shape[1] != self.spec.input_dim[m]:
                 raise ValueError("batch[%r] has shape %s, expected (N, %d)" % (
@@ -226,15 +268,18 @@ class MoPoEEngine:
         return plan, ws
 
     def train_step(self, batch, eps=None, row_index=None, apply_adam=True,
-                   stats_host=None, comm=None):
+                   stats_host=None, comm=None, loss_scale=1.0):
         """mopoe_train_step: forward + backward (+ fused Adam).  `stats_host`:
         a pinned host tensor the kernel writes the step's scalars into (the
         per-step log without a copy on the stream; read it after a sync or a
         few steps later).  `comm` (an XgmiComm): mopoe_comm_train_step -- the
         weight-gradient launch exchanges its blocks with the other ranks and
-        applies Adam with the mean (all ranks: same modalities in the batch)."""
+        applies Adam with the mean (all ranks: same modalities in the batch).
+        `loss_scale`: weight of the batch's loss terms (parallel.py)."""
+        self.check_valid()          # (pinned host mirror: no synchronisation)
         x, n, row_index = self._prepare(batch, row_index)
-        plan = self.spec.plan(list(x.keys()), n, True, None, True, True)
+        plan = self.spec.plan(list(x.keys()), n, True, None, True, True,
+                              loss_scale=loss_scale)
         slots = max(plan.jobs_per_mod)
         ws = self.workspace(n, slots, True)
         step = plan.c_step
@@ -253,11 +298,12 @@ class MoPoEEngine:
                                            L.stream_ptr()), "mopoe_train_step")
         self._keep = (x, keep, row_index)
         self.last_present_mask = step.present_mask
-        self._host_step += 1
         return plan, ws
 
-    def adam_step(self, present_mask=None, grad_scale=1.0):
-        """mopoe_adam_step on the flat buffers (after a gradient all-reduce)."""
+    def adam_step(self, present_mask=None, world=1):
+        """mopoe_adam_step on the flat buffers.  `world` > 1: engine.grads holds the
+        SUM over `world` data-parallel ranks (after an all-reduce); the kernel applies
+        the mean and checks that every rank's batch held the same modalities."""
         L.require_gpu()
         if present_mask is None:
             present_mask = self.last_present_mask
@@ -267,10 +313,27 @@ class MoPoEEngine:
         b.exp_avg = L.ptr(self.exp_avg)
         b.exp_avg_sq = L.ptr(self.exp_avg_sq)
         b.counters = L.ptr(self.counters)
+        b.status_host = L.ptr(self.status_host)
         L.check(L.lib.mopoe_adam_step(self.spec.c_model, present_mask, b,
-                                      C.byref(self.adam), grad_scale,
-                                      self._host_step, L.stream_ptr()),
+                                      C.byref(self.adam), int(world), L.stream_ptr()),
                 "mopoe_adam_step")
+
+    def decode(self, content, styles):
+        """Decoder.forward of every modality in `styles` (networks.py:66-77) on given
+        latents: {name: (loc (N, d_m), scale (1, d_m))}; loc = [style | content] Wd^T +
+        bd through mopoe_linear, scale = exp(logvar / 2)."""
+        from . import ops
+        out = OrderedDict()
+        for m, name in enumerate(self.spec.names):
+            if name not in styles:
+                continue
+            z = content
+            if self.spec.has_style(m):
+                z = torch.cat((styles[name].to(content.device), content), dim=1)
+            k = "decoders.%s." % name
+            loc = ops.linear(z, self.views[k + "out_mu.weight"], self.views[k + "out_mu.bias"])
+            out[name] = (loc, (self.views[k + "logvar"] * 0.5).exp())
+        return out
 
     # --------------------------------------------------------------- results
     def results(self, plan, ws):

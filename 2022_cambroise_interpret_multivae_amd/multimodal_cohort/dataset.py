@@ -99,23 +99,39 @@ class MultimodalDataset(torch.utils.data.Dataset):
 
 
 class MissingModalitySampler(torch.utils.data.Sampler):
-    """reference dataset.py:275-354 (non-stratified path)."""
+    """reference dataset.py:275-354 (non-stratified path).
+
+    `world` > 1 (data-parallel replicas, one process per GPU): the epoch is the
+    reference's own draw for batches of `batch_size * world` samples -- made by rank 0
+    and shared, so every rank deals from the same schedule -- and rank `rank` yields
+    its contiguous share of every global batch.  All ranks therefore step on batches
+    that hold the SAME modalities, which torch's per-parameter Adam step counts need
+    (parallel.py).  `loss_scales[k]` is the weight n_r * world / n_global of this rank's
+    k-th batch (1.0 when the global batch splits evenly; a rank left without a sample by
+    a ragged batch re-uses one with weight 0)."""
 
     def __init__(self, dataset, batch_size, indices=None, stratify=None,
-                 discretize=None, seed=42):
+                 discretize=None, seed=42, world=1, rank=0):
         if stratify is not None:
             raise NotImplementedError("stratified batches need iterstrat "
                                       "(MultilabelStratifiedKFold), absent from this image")
+        if not 0 <= rank < world:
+            raise ValueError("rank %d outside world %d" % (rank, world))
         self.dataset = dataset
         self.indices = indices
         self.batch_size = batch_size
         self.seed = seed
+        self.world = world
+        self.rank = rank
+        self.loss_scales = []
 
     def __len__(self):
-        return sum((len(idx) + self.batch_size - 1) // self.batch_size
+        size = self.batch_size * self.world
+        return sum((len(idx) + size - 1) // size
                    for idx in self.dataset.idx_per_modality_subset)
 
-    def __iter__(self):
+    def draw(self, batch_size):
+        """The reference's epoch for this batch size (its np.random stream)."""
         indices, complete, incomplete = [], [], []
         batch_idx = 0
         for idx, _ in enumerate(self.dataset.modality_subsets):
@@ -130,8 +146,8 @@ class MissingModalitySampler(torch.utils.data.Sampler):
                 self.dataset._subset_arrays = cache   # the index lists as arrays, built once
             mod_subset_idx = cache[1][idx]
             while len(mod_subset_idx) > 0:
-                size = min(len(mod_subset_idx), self.batch_size)
-                (incomplete if size < self.batch_size else complete).append(batch_idx)
+                size = min(len(mod_subset_idx), batch_size)
+                (incomplete if size < batch_size else complete).append(batch_idx)
                 # == np.random.choice(mod_subset_idx, size, replace=False): the legacy
                 # (frozen) RandomState draws permutation(len)[:size] for it
                 pick = np.random.permutation(len(mod_subset_idx))[:size]
@@ -141,8 +157,34 @@ class MissingModalitySampler(torch.utils.data.Sampler):
                 batch_idx += 1
         complete_order = np.random.choice(complete, size=len(complete), replace=False)
         incomplete_order = np.random.choice(incomplete, size=len(incomplete), replace=False)
-        ordered = [indices[i] for i in complete_order] + [indices[i] for i in incomplete_order]
-        return iter(ordered)
+        return [indices[i] for i in complete_order] + [indices[i] for i in incomplete_order]
+
+    def shares(self, global_batches):
+        """This rank's part of every global batch + its weight in the ranks' mean."""
+        W, r = self.world, self.rank
+        mine, scales = [], []
+        for b in global_batches:
+            n = len(b)
+            base, rem = divmod(n, W)
+            lo = r * base + min(r, rem)
+            hi = lo + base + (1 if r < rem else 0)
+            if hi > lo:
+                mine.append(b[lo:hi])
+                scales.append((hi - lo) * W / float(n))
+            else:           # fewer samples than ranks: take part with weight 0
+                mine.append(b[:1])
+                scales.append(0.0)
+        return mine, scales
+
+    def __iter__(self):
+        if self.world == 1:
+            batches = self.draw(self.batch_size)
+            self.loss_scales = [1.0] * len(batches)
+            return iter(batches)
+        from ..parallel import share_schedule
+        glob = self.draw(self.batch_size * self.world) if self.rank == 0 else None
+        mine, self.loss_scales = self.shares(share_schedule(glob))
+        return iter(mine)
 
 
 class ResidentCohort:
@@ -161,7 +203,7 @@ class ResidentCohort:
                 mean, scale = scalers[mod]
                 arr = (arr - torch.as_tensor(mean, dtype=torch.float64)) / \
                     torch.as_tensor(scale, dtype=torch.float64)
-            self.x[mod] = L.rows_with_slack(arr.to(torch.float32), self.device)
+            self.x[mod] = L.device_rows(arr.to(torch.float32), self.device)
         self._indices = None   # dataset.indices as an array, built on first use
         # block row of every subject, -1 where the modality is missing
         self.rows = {}
@@ -191,7 +233,14 @@ class ResidentCohort:
     def epoch(self, batch_size):
         """One epoch of (inputs, row_index) in MissingModalitySampler order; all
         index vectors go to the device in one transfer."""
-        batches = list(MissingModalitySampler(self.dataset, batch_size))
+        return [(i, r) for i, r, _ in self.epoch_schedule(batch_size)]
+
+    def epoch_schedule(self, batch_size, world=1, rank=0):
+        """One epoch of (inputs, row_index, loss_scale) for rank `rank` of `world`
+        data-parallel replicas (MissingModalitySampler's rank-aware schedule)."""
+        sampler = MissingModalitySampler(self.dataset, batch_size, world=world, rank=rank)
+        batches = list(sampler)
+        scales = list(sampler.loss_scales)
         out = []
         flat, spans, start = [], [], 0
         for b in batches:
@@ -200,7 +249,7 @@ class ResidentCohort:
                 spans.append((len(out), mod, start, len(r)))
                 flat.append(r)
                 start += len(r)
-            out.append((inputs, {}))
+            out.append((inputs, {}, scales[len(out)]))
         if flat:
             dev = torch.cat(flat).to(self.device, non_blocking=True)
             for bi, mod, start, n in spans:

@@ -14,7 +14,7 @@ def _f32(t):
 
 def linear(x, weight, bias=None, relu=False):
     """y = act(x @ weight^T + bias) through mopoe_linear (MFMA kernel)."""
-    x, weight = L.rows_with_slack(_f32(x)), _f32(weight)
+    x, weight = _f32(x), _f32(weight)
     bias = None if bias is None else _f32(bias)
     n, k = x.shape
     ncols = weight.shape[0]

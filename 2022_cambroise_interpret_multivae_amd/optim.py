@@ -12,7 +12,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.model = model
         super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps))
         self._sync()
-        self.grad_scale = 1.0
+        self.world = 1     # > 1: engine.grads holds the sum over that many ranks
 
     def _sync(self):
         g = self.param_groups[0]
@@ -24,4 +24,4 @@ class FusedAdam(torch.optim.Optimizer):
             raise NotImplementedError("closure")
         self._sync()
         eng = self.model.engine
-        eng.adam_step(present_mask=eng.last_present_mask, grad_scale=self.grad_scale)
+        eng.adam_step(present_mask=eng.last_present_mask, world=self.world)

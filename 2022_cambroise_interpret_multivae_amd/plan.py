@@ -29,7 +29,7 @@ class ModelSpec:
                  method="joint_elbo", factorized=True, beta=1.0,
                  beta_style=1.0, beta_content=1.0, initial_out_logvar=-3.0,
                  learn_output_scale=True, lr=0.002, betas=(0.9, 0.999),
-                 adam_eps=1e-8, rec_weights=None):
+                 adam_eps=1e-8, rec_weights=None, poe_unimodal_elbos=True):
         if method not in METHODS:
             raise NotImplementedError(
                 "method %r: only joint_elbo / poe / moe are on the MI355X hot "
@@ -57,6 +57,9 @@ class ModelSpec:
         self.lr = float(lr)
         self.betas = (float(betas[0]), float(betas[1]))
         self.adam_eps = float(adam_eps)
+        # run_epochs.py:115: method poe adds the unimodal ELBOs (one extra forward per
+        # modality) only when this flag is set
+        self.poe_unimodal_elbos = bool(poe_unimodal_elbos)
         self.rec_weights = dict(rec_weights) if rec_weights else \
             {n: 1.0 for n in self.names}
 
@@ -106,7 +109,8 @@ class ModelSpec:
                    learn_output_scale=flags.learn_output_scale,
                    lr=getattr(flags, "initial_learning_rate", 0.002),
                    betas=(getattr(flags, "beta_1", 0.9),
-                          getattr(flags, "beta_2", 0.999)))
+                          getattr(flags, "beta_2", 0.999)),
+                   poe_unimodal_elbos=getattr(flags, "poe_unimodal_elbos", True))
 
     @property
     def num_mods(self):
@@ -161,12 +165,14 @@ class ModelSpec:
 
     # ------------------------------------------------------------------
     def plan(self, present, n, sample=True, use_expert=None, backward=False,
-             loss=False, group_rows=0):
+             loss=False, group_rows=0, loss_scale=1.0):
         """`loss`: also run the decoder passes that only the loss needs (the
         unimodal forwards of method poe, run_epochs.py:104-128).  `group_rows`:
-        the n rows are n/group_rows independent batches (mopoe_step.group_rows)."""
+        the n rows are n/group_rows independent batches (mopoe_step.group_rows).
+        `loss_scale`: weight of this batch's loss terms -- n_r * world / n_global for a
+        data-parallel rank whose share of the global batch is ragged (parallel.py)."""
         key = (tuple(present), int(n), bool(sample), use_expert, bool(backward),
-               bool(loss or backward), int(group_rows))
+               bool(loss or backward), int(group_rows), float(loss_scale))
         p = self._plans.get(key)
         if p is None:
             p = StepPlan(self, *key)
@@ -187,7 +193,7 @@ class StepPlan:
     """One `mopoe_step` descriptor + the bookkeeping to read results back."""
 
     def __init__(self, spec, present, n, sample, use_expert, backward, loss,
-                 group_rows=0):
+                 group_rows=0, loss_scale=1.0):
         self.spec = spec
         self.n = n
         if group_rows and (n % group_rows or backward):
@@ -268,7 +274,8 @@ class StepPlan:
         jobs = []          # (modality index, slot, src subset or -1, pass)
         for m in self.present_idx:
             jobs.append((m, 0, -1, 0))
-        if spec.method == "poe" and loss:
+        unimodal = spec.method == "poe" and spec.poe_unimodal_elbos
+        if unimodal and loss:
             for p, nm in enumerate(self.present):     # run_epochs.py:107 order
                 m = names.index(nm)
                 jobs.append((m, 1, spec.subset_keys.index(nm), 1 + p))
@@ -305,13 +312,22 @@ class StepPlan:
         else:                                        # run_epochs.py:104-128
             coef = [0.0] * len(spec.subset_keys)
             coef[comp[0]] += b * bc                  # elbo_joint: K = 1, w = 1
-            for nm in self.present:                  # unimodal elbos use klds[m]
-                coef[spec.subset_keys.index(nm)] += b * bc
+            if unimodal:
+                for nm in self.present:              # unimodal elbos use klds[m]
+                    coef[spec.subset_keys.index(nm)] += b * bc
             for s, v in enumerate(coef):
                 st.sub_kl_coef[s] = v
-            for m in self.present_idx:
+            for m in self.present_idx:               # style KL: joint elbo (+ unimodal one)
                 if spec.has_style(m):
-                    st.style_kl_coef[m] = 2.0 * b * bs * bs
+                    st.style_kl_coef[m] = (2.0 if unimodal else 1.0) * b * bs * bs
+        self.loss_scale = float(loss_scale)
+        if self.loss_scale != 1.0:
+            for s in range(L.MAX_SUBSETS):
+                st.sub_kl_coef[s] *= self.loss_scale
+            for m in range(L.MAX_MODS):
+                st.style_kl_coef[m] *= self.loss_scale
+            for j in range(L.MAX_JOBS):
+                st.job_nll_coef[j] *= self.loss_scale
         self.c_step = st
 
     def lds_bytes(self):

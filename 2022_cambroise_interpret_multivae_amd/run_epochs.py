@@ -9,12 +9,11 @@ returns the loss terms; with grad enabled it runs the fused forward+backward
 reference's `optimizer.zero_grad(); total_loss.backward(); optimizer.step()`
 sequence (run_epochs.py:180-182) is unchanged.
 """
-import os
-
 import torch
 from torch.utils.data import DataLoader
 
 from . import _lib as L
+from . import checkpoint, parallel
 
 
 class _FusedLoss(torch.autograd.Function):
@@ -29,6 +28,9 @@ class _FusedLoss(torch.autograd.Function):
     def backward(ctx, grad_out):
         model = ctx.model
         eng = model.engine
+        # the gradients already sit in engine.grads for d(total_loss) = 1; a caller that
+        # scales the loss before .backward() gets them scaled (one in-place multiply)
+        eng.grads.mul_(grad_out)
         mask = eng.last_present_mask
         names = eng.spec.names
         for name, p in model.named_parameters():
@@ -119,11 +121,26 @@ def basic_routine_epoch(exp, model_idx, batch):
             "total_loss": total_loss, "klds": _Lazy(lambda: sc["klds"])}
 
 
+def _log_step(tb_logger, eng, plan, ws):
+    if tb_logger is not None:
+        sc = eng.scalars(plan, ws)
+        tb_logger.write_training_logs(eng.results(plan, ws), sc["total_loss"],
+                                      sc["log_probs"], sc["klds"])
+
+
 def train(model_idx, epoch, exp, tb_logger):
-    """reference run_epochs.py:138-184.  When `exp.dataset_train` is a
-    dataset.ResidentCohort the epoch runs on index batches over HBM-resident
-    blocks (no per-sample host work); otherwise batches come from a DataLoader
-    exactly as in the reference."""
+    """reference run_epochs.py:138-184.
+
+    * `exp.dataset_train` a dataset.ResidentCohort: the epoch runs on index batches
+      over HBM-resident blocks (no per-sample host work), one fused launch pair per
+      step.  Under torch.distributed (one process per GPU) the ranks are data-parallel
+      replicas: the rank-aware MissingModalitySampler deals every global batch of
+      batch_size * world samples out over the ranks (all ranks: the same modalities),
+      and parallel.DataParallelStep exchanges the gradients and applies Adam with the
+      mean (RCCL all-reduce unless `exp.dp_exchange` / `exp.dp_comm` choose the
+      peer-window forms).
+    * otherwise batches come from a DataLoader exactly as in the reference and the
+      step keeps the reference's shape: zero_grad / backward / optimizer.step."""
     model, dataset, optimizer = exp.models, exp.dataset_train, exp.optimizers
     if exp.flags.num_models > 1:
         model, dataset, optimizer = model[model_idx], dataset[model_idx], optimizer[model_idx]
@@ -131,16 +148,24 @@ def train(model_idx, epoch, exp, tb_logger):
     if getattr(exp.flags, "grad_scaling", False):
         raise NotImplementedError("grad_scaling (the reference's branch never calls "
                                   "zero_grad, SURVEY.md appendix C)")
-    if hasattr(dataset, "epoch"):                      # ResidentCohort
-        eng = model.engine
-        for inputs, row_index in dataset.epoch(exp.flags.batch_size):
+    eng = model.engine
+    world = parallel.world_size()
+    if hasattr(dataset, "epoch_schedule"):             # ResidentCohort
+        step = _dp_step(exp, model_idx, eng) if world > 1 else None
+        for inputs, row_index, weight in dataset.epoch_schedule(
+                exp.flags.batch_size, world, parallel.rank()):
             optimizer._sync()
-            plan, ws = eng.train_step(inputs, row_index=row_index, apply_adam=True)
-            if tb_logger is not None:
-                sc = eng.scalars(plan, ws)
-                tb_logger.write_training_logs(eng.results(plan, ws), sc["total_loss"],
-                                              sc["log_probs"], sc["klds"])
+            if step is None:
+                plan, ws = eng.train_step(inputs, row_index=row_index, apply_adam=True)
+            else:
+                plan, ws = step(inputs, row_index=row_index, loss_scale=weight)
+            _log_step(tb_logger, eng, plan, ws)
+        eng.check_valid(sync=True)      # no half-applied step leaves the epoch unnoticed
         return
+    if world > 1:
+        raise NotImplementedError(
+            "data-parallel training runs over a dataset.ResidentCohort (the DataLoader "
+            "path keeps the reference's single-process zero_grad / backward / step)")
     for batch in _loader(exp, dataset, train=True):
         basic_routine = basic_routine_epoch(exp, model_idx, batch)
         optimizer.zero_grad()
@@ -150,6 +175,18 @@ def train(model_idx, epoch, exp, tb_logger):
             tb_logger.write_training_logs(basic_routine["results"],
                                           basic_routine["total_loss"],
                                           basic_routine["log_probs"], basic_routine["klds"])
+    eng.check_valid(sync=True)
+
+
+def _dp_step(exp, model_idx, eng):
+    """The model's DataParallelStep, made once (its constructor broadcasts rank 0's
+    parameters, moments and step counts)."""
+    steps = exp.__dict__.setdefault("_dp_steps", {})
+    if model_idx not in steps:
+        steps[model_idx] = parallel.DataParallelStep(
+            eng, comm=getattr(exp, "dp_comm", None),
+            exchange=getattr(exp, "dp_exchange", None))
+    return steps[model_idx]
 
 
 def test(model_idx, epoch, exp, tb_logger):
@@ -183,22 +220,16 @@ def _loader(exp, dataset, train):
 
 
 def run_epochs(exp, tb_logger=None):
-    """reference run_epochs.py:222-256: epochs of train + test, checkpoints
-    every 5 epochs under <dir_checkpoints>/<epoch:04d>/<model_save>."""
-    for model_idx in range(exp.flags.num_models):
-        for epoch in range(exp.flags.start_epoch, exp.flags.end_epoch):
+    """reference run_epochs.py:222-256: epochs of train + test; a checkpoint every fifth
+    epoch and after the last one, in the reference's layout (checkpoint.py).  Data-
+    parallel replicas hold identical parameters: rank 0 writes."""
+    flags = exp.flags
+    many = flags.num_models > 1
+    for model_idx in range(flags.num_models):
+        for epoch in range(flags.start_epoch, flags.end_epoch):
             train(model_idx, epoch, exp, tb_logger)
             test(model_idx, epoch, exp, tb_logger)
-            if (epoch + 1) % 5 == 0 or (epoch + 1) == exp.flags.end_epoch:
-                model = exp.models
-                dir_network_epoch = os.path.join(exp.flags.dir_checkpoints,
-                                                 str(epoch).zfill(4))
-                if exp.flags.num_models > 1:
-                    model = model[model_idx]
-                    dir_network_epoch = os.path.join(
-                        exp.flags.dir_checkpoints, "model_%d" % model_idx,
-                        str(epoch).zfill(4))
-                os.makedirs(dir_network_epoch, exist_ok=True)
-                model.save_networks()
-                torch.save(model.state_dict(),
-                           os.path.join(dir_network_epoch, exp.flags.model_save))
+            due = (epoch + 1) % 5 == 0 or epoch + 1 == flags.end_epoch
+            if due and parallel.rank() == 0:
+                checkpoint.save_model(exp.models[model_idx] if many else exp.models, flags,
+                                      epoch, model_idx if many else None)

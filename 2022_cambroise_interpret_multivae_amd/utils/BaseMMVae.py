@@ -4,12 +4,10 @@ engine.  The parameters of the encoder / decoder sub-modules are views of one
 flat device buffer; `forward` / `inference` run the fused forward kernels
 (no autograd graph: training goes through run_epochs.basic_routine_epoch,
 whose total_loss carries the HIP backward)."""
-import os
-
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import checkpoint, ops
 from ..engine import MoPoEEngine
 from ..plan import ModelSpec
 from ..divergence_measures.mm_div import calc_group_divergence_moe, poe
@@ -149,70 +147,57 @@ class BaseMMVae(nn.Module):
         return self.engine.results(plan, ws)["latents"]
 
     # ------------------------------------------------------------ generation
-    def generate(self, num_samples=None):
-        """reference BaseMMVae.py:242-255"""
-        if num_samples is None:
-            num_samples = self.flags.batch_size
-        dev = self.engine.device
-        mu = torch.zeros(num_samples, self.flags.class_dim, device=dev)
-        z_class = self.reparameterize(mu, torch.zeros_like(mu))
-        z_styles = self.get_random_styles(num_samples)
-        return self.generate_from_latents({"content": z_class, "style": z_styles})
-
-    def generate_sufficient_statistics_from_latents(self, latents):
-        """reference BaseMMVae.py:258-266"""
-        suff_stats = dict()
-        content = latents["content"]
-        for m_key in self.modalities.keys():
-            s = latents["style"][m_key]
-            loc, scale = self.decoders[m_key](s, content)
-            suff_stats[m_key] = self.lhoods[m_key](loc, scale, validate_args=False)
-        return suff_stats
-
-    def generate_from_latents(self, latents):
-        """reference BaseMMVae.py:269-275"""
-        suff_stats = self.generate_sufficient_statistics_from_latents(latents)
-        return {m_key: suff_stats[m_key].mean for m_key in latents["style"].keys()}
-
-    def cond_generation(self, latent_distributions, num_samples=None):
-        """reference BaseMMVae.py:278-290"""
-        if num_samples is None:
-            num_samples = len(list(latent_distributions.values())[0][0])
-        style_latents = self.get_random_styles(num_samples)
-        cond_gen_samples = dict()
-        for key, (mu, logvar) in latent_distributions.items():
-            content_rep = self.reparameterize(mu=mu, logvar=logvar)
-            latents = {"content": content_rep, "style": style_latents}
-            cond_gen_samples[key] = self.generate_from_latents(latents)
-        return cond_gen_samples
+    # (reference BaseMMVae.py:242-322.  Everything below is "draw latents, run the
+    # decoders": engine.decode is one mopoe_linear per modality on [style | content].)
+    def _prior_draw(self, num_samples, dim):
+        """z ~ N(0, I) of shape (num_samples, dim) from the device generator."""
+        zero = torch.zeros(num_samples, dim, device=self.engine.device)
+        return self.reparameterize(zero, zero)
 
     def get_random_style_dists(self, num_samples):
-        """reference BaseMMVae.py:293-303"""
-        styles = dict()
-        for m_key in self.modalities.keys():
-            mod = self.modalities[m_key]
-            s_mu = torch.zeros(num_samples, mod.style_dim, device=self.engine.device)
-            styles[m_key] = [s_mu, torch.zeros_like(s_mu)]
-        return styles
+        """{modality: [mu, logvar]} of the style prior N(0, I) (reference :293-303)."""
+        dev = self.engine.device
+        return {name: [torch.zeros(num_samples, mod.style_dim, device=dev),
+                       torch.zeros(num_samples, mod.style_dim, device=dev)]
+                for name, mod in self.modalities.items()}
 
     def get_random_styles(self, num_samples):
-        """reference BaseMMVae.py:306-316"""
-        styles = dict()
-        for k, m_key in enumerate(self.modalities.keys()):
-            if self.flags.factorized_representation and self.flags.style_dim[k] > 0:
-                mod = self.modalities[m_key]
-                mu = torch.zeros(num_samples, mod.style_dim, device=self.engine.device)
-                styles[m_key] = self.reparameterize(mu, torch.zeros_like(mu))
-            else:
-                styles[m_key] = None
-        return styles
+        """{modality: style sample from the prior, or None without a style branch}
+        (reference :306-316)."""
+        return {name: self._prior_draw(num_samples, self.spec.style_dim[m])
+                if self.spec.has_style(m) else None
+                for m, name in enumerate(self.modalities)}
+
+    def generate_sufficient_statistics_from_latents(self, latents):
+        """{modality: likelihood(loc, scale)} for content / style latents
+        (reference :258-266)."""
+        decoded = self.engine.decode(latents["content"], latents["style"])
+        return {name: self.lhoods[name](loc, scale, validate_args=False)
+                for name, (loc, scale) in decoded.items()}
+
+    def generate_from_latents(self, latents):
+        """{modality: mean of its likelihood} (reference :269-275)."""
+        stats = self.generate_sufficient_statistics_from_latents(latents)
+        return {name: stats[name].mean for name in latents["style"]}
+
+    def generate(self, num_samples=None):
+        """Unconditional samples: content and styles from the prior (reference :242-255)."""
+        n = self.flags.batch_size if num_samples is None else num_samples
+        return self.generate_from_latents(
+            {"content": self._prior_draw(n, self.flags.class_dim),
+             "style": self.get_random_styles(n)})
+
+    def cond_generation(self, latent_distributions, num_samples=None):
+        """{key: generations} for every given content posterior [mu, logvar]; one draw
+        of prior styles serves all keys (reference :278-290)."""
+        if num_samples is None:
+            num_samples = len(next(iter(latent_distributions.values()))[0])
+        styles = self.get_random_styles(num_samples)
+        return {key: self.generate_from_latents(
+                    {"content": self.reparameterize(mu=mu, logvar=logvar), "style": styles})
+                for key, (mu, logvar) in latent_distributions.items()}
 
     def save_networks(self):
-        """reference BaseMMVae.py:315-322"""
-        for m_key in self.modalities.keys():
-            torch.save(self.encoders[m_key].state_dict(),
-                       os.path.join(self.flags.dir_checkpoints,
-                                    "enc_" + self.modalities[m_key].name))
-            torch.save(self.decoders[m_key].state_dict(),
-                       os.path.join(self.flags.dir_checkpoints,
-                                    "dec_" + self.modalities[m_key].name))
+        """Per-modality state dicts `enc_<name>` / `dec_<name>` under
+        flags.dir_checkpoints (reference :315-322)."""
+        checkpoint.save_networks(self, self.flags.dir_checkpoints)

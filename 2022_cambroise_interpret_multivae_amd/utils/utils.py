@@ -33,24 +33,24 @@ def mixture_component_selection(flags, mus, logvars, w_modalities=None):
 
 
 def calc_elbo(exp, modality, recs, klds):
-    """reference utils/utils.py:88-112"""
+    """ELBO of one modality or of the joint posterior from its already computed terms
+    (reference utils/utils.py:88-112; the fused step folds the same weights into the
+    loss coefficients of plan.py, this function serves callers that hold the terms):
+
+        rec + beta * (beta_content * KL_content + beta_style * KL_style)
+
+    `recs` / `klds["style"]` are keyed by modality name; for "joint" the reconstruction
+    and style terms are the rec_weights- / style_weights-weighted sums over the
+    modalities that have a style term, for a single modality its own (weight 1 on the
+    reconstruction, style_weights[m] on the style KL)."""
     flags = exp.flags
-    mods = exp.modalities
-    s_weights = exp.style_weights
-    r_weights = exp.rec_weights
-    kld_content = klds["content"]
+    style = klds["style"]
     if modality == "joint":
-        w_style_kld = 0.0
-        w_rec = 0.0
-        klds_style = klds["style"]
-        for m_key in mods.keys():
-            if m_key in klds_style.keys():
-                w_style_kld += s_weights[m_key] * klds_style[m_key]
-                w_rec += r_weights[m_key] * recs[m_key]
-        kld_style = w_style_kld
-        rec_error = w_rec
+        names = [m for m in exp.modalities if m in style]
+        rec = sum(exp.rec_weights[m] * recs[m] for m in names)
+        kl_style = sum(exp.style_weights[m] * style[m] for m in names)
     else:
-        kld_style = s_weights[modality] * klds["style"][modality]
-        rec_error = 1.0 * recs[modality]
-    div = flags.beta_content * kld_content + flags.beta_style * kld_style
-    return rec_error + flags.beta * div
+        rec = 1.0 * recs[modality]
+        kl_style = exp.style_weights[modality] * style[modality]
+    return rec + flags.beta * (flags.beta_content * klds["content"] +
+                               flags.beta_style * kl_style)

@@ -118,9 +118,7 @@ def make_pool(device):
     g = torch.Generator().manual_seed(1234)
     pool = []
     for _ in range(POOL):
-        # (rows_with_slack: device copies readable 16 bytes past their last row, the
-        #  contract of the input matrices -- the engine would otherwise copy per step)
-        pool.append({n: mm._lib.rows_with_slack(torch.randn(BATCH, d, generator=g), device)
+        pool.append({n: torch.randn(BATCH, d, generator=g).to(device)
                      for n, d in zip(NAMES, DIMS)})
     return pool
 
@@ -221,7 +219,7 @@ def check_in_backward(comm, spec, batch, device, world, dist):
             for q in parts[1:]:
                 total += q
             b.grads.copy_(total)
-            b.adam_step(grad_scale=1.0 / world)
+            b.adam_step(world=world)
         torch.cuda.synchronize()
         if not (torch.equal(a.params, b.params) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)):
             ok = 0.0
@@ -300,7 +298,7 @@ def main():
             comm.allreduce_adam(eng)                # one launch: push, sum, Adam
         elif not fused:
             dist.all_reduce(eng.grads)              # RCCL, one flat buffer
-            eng.adam_step(grad_scale=1.0 / world)
+            eng.adam_step(world=world)
         return ws
 
     def barrier():
@@ -346,8 +344,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(ws.stats[0].item())
-    if int(eng.counters[2].item()) != 0:
-        sys.exit("a hand-off inside the fused launch timed out")
+    eng.check_valid(sync=True)     # (raises if any step of the timed region was invalid)
     if not args.no_log_copy:   # the host ring must have received the same scalar
         host = float(log_ring[(args.warmup + args.steps - 1) % 8][0])
         if host != loss:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 5
+#define MOPOE_ABI_VERSION 6
 #define MOPOE_MAX_MODS 5      /* modalities                                   */
 #define MOPOE_MAX_SUBSETS 31  /* 2^MAX_MODS - 1 non-empty subsets             */
 #define MOPOE_MAX_JOBS 10     /* decoder passes: 1 joint + 1 unimodal per mod */
@@ -57,7 +57,31 @@ extern "C" {
 #define MOPOE_STAT_KLD_SUBSET 2                        /* + subset index       */
 #define MOPOE_STAT_KLD_STYLE (2 + MOPOE_MAX_SUBSETS)   /* + modality index     */
 #define MOPOE_STAT_NLL (MOPOE_STAT_KLD_STYLE + MOPOE_MAX_MODS) /* + job index  */
-#define MOPOE_NUM_STATS (MOPOE_STAT_NLL + MOPOE_MAX_JOBS)
+/* utils/TBLogger.py:26-37 (write_latent_distr): mean over the batch and the latent
+ * dimensions of every encoder output, + 4 * modality + {0 style mu, 1 style logvar,
+ * 2 content mu, 3 content logvar} */
+#define MOPOE_STAT_LATENT_MEAN (MOPOE_STAT_NLL + MOPOE_MAX_JOBS)
+#define MOPOE_NUM_STATS (MOPOE_STAT_LATENT_MEAN + 4 * MOPOE_MAX_MODS)
+
+/* the int32 `counters` buffer (device), zeroed once by the caller */
+#define MOPOE_NUM_COUNTERS 64
+#define MOPOE_CTR_STEPS_BEGUN 0   /* training steps begun                            */
+#define MOPOE_CTR_STEPS_DONE 1    /* training steps whose last kernel has finished   */
+#define MOPOE_CTR_INVALID 2       /* != 0: a step could not be completed (a hand-off
+                                     inside the fused launch or a wait of the gradient
+                                     exchange timed out, or the ranks' batches held
+                                     different modalities).  STICKY: while it is
+                                     non-zero no Adam update is applied; the caller
+                                     reads it (or its mirror in status_host), raises,
+                                     and re-zeroes `partials` and this word to go on */
+#define MOPOE_CTR_ADAM_STEPS 4    /* + modality: Adam updates applied to that
+                                     modality's parameters (torch.optim.Adam keeps
+                                     state['step'] per parameter and skips parameters
+                                     whose .grad is None: an encoder / decoder whose
+                                     modality sat out k batches is k steps behind)   */
+#define MOPOE_CTR_TICKET 9        /* last-block detection of the Adam kernel (0)     */
+#define MOPOE_CTR_BIAS 16         /* 2 slots (step parity) x MAX_MODS records of 4
+                                     words: the bias corrections of the step          */
 
 /* ---------------------------------------------------------------------------
  * Model description: replaces the flags the reference's Encoder / Decoder /
@@ -74,6 +98,7 @@ extern "C" {
  *   wd  (d_m, zd_m)     decoders.<m>.out_mu.weight, zd_m = style_dim[m]+class_dim
  *   bd  (d_m)           decoders.<m>.out_mu.bias
  *   lvo (d_m)           decoders.<m>.logvar  (1, d_m)
+ * followed by 64 control words (off_ctrl) that are no parameters.
  * ------------------------------------------------------------------------- */
 typedef struct mopoe_model {
     int32_t num_mods;
@@ -89,6 +114,10 @@ typedef struct mopoe_model {
     int32_t off_wd[MOPOE_MAX_MODS];
     int32_t off_bd[MOPOE_MAX_MODS];
     int32_t off_lvo[MOPOE_MAX_MODS];
+    int32_t off_ctrl;                  /* 64 control words behind the last segment: in
+                                          buf->grads, word m = 1.0 if modality m was in
+                                          the step's batch (summed by the ranks'
+                                          all-reduce, checked by the Adam kernel)    */
     int32_t num_floats;                /* length of the flat buffer            */
 } mopoe_model;
 
@@ -166,20 +195,18 @@ typedef struct mopoe_buffers {
     float* grads;                        /* (num_floats)  written by backward  */
     float* exp_avg;                      /* (num_floats)  Adam m               */
     float* exp_avg_sq;                   /* (num_floats)  Adam v               */
-    int32_t* counters;                   /* (16) [0] steps begun, [1] steps done,
-                                            [2] != 0: a hand-off inside the fused
-                                            launch timed out (results invalid),
-                                            [3..10] Adam coefficients of step [0] */
+    int32_t* counters;                   /* (MOPOE_NUM_COUNTERS) MOPOE_CTR_*      */
 
-    const float* x[MOPOE_MAX_MODS];      /* (rows, d_m) input, ld = d_m.  Must be
-                                            readable for 16 bytes past its last row:
-                                            rows are read with 16-byte loads, and with
-                                            d_m % 4 != 0 the load over a row's tail
-                                            also covers the next row's start (masked) */
+    const float* x[MOPOE_MAX_MODS];      /* (x_rows[m], d_m) input, ld = d_m; nothing
+                                            past x_rows[m] * d_m floats is touched  */
     const int32_t* row_index[MOPOE_MAX_MODS]; /* optional (n) per modality: row of
                                             x[m] that holds batch row i (a batch
                                             is then a gather out of cohort arrays
-                                            resident in HBM); NULL = identity   */
+                                            resident in HBM); NULL = identity.  An
+                                            index outside [0, x_rows[m]) reads as a
+                                            row of zeros                          */
+    int32_t x_rows[MOPOE_MAX_MODS];      /* rows of x[m]: required with row_index[m]
+                                            (the cohort's rows), else 0 or n       */
 
     float* hidden[MOPOE_MAX_MODS];       /* (n, 256)     relu(x W1^T + b1)     */
     float* heads[MOPOE_MAX_MODS];        /* (n, nh_m)    encoder outputs       */
@@ -195,16 +222,21 @@ typedef struct mopoe_buffers {
                                             are also written there by the kernel
                                             itself (a log without a D2H copy on
                                             the stream); NULL to skip           */
+    int32_t* status_host;                /* optional: pinned HOST memory (4 int32):
+                                            the last kernel of every training step
+                                            writes {steps done, MOPOE_CTR_INVALID,
+                                            0, 0} there, so the caller can notice an
+                                            invalid step without synchronising    */
 
     float* g_xhat[MOPOE_MAX_MODS];       /* (R_m, d_m)   d loss / d loc        */
     float* g_heads[MOPOE_MAX_MODS];      /* (n, nh_m)                          */
     float* g_pre[MOPOE_MAX_MODS];        /* (n, 256)     d loss / d pre-relu   */
     float* partials;                     /* (mopoe_row_groups(model, step),
                                             mopoe_partials_stride(model)); ZERO it
-                                            once after allocating: word 63 of a
+                                            once after allocating: one word of a
                                             slab is the row group's hand-off flag
                                             in the fused launch, left at zero by
-                                            every call                          */
+                                            every call that completes             */
 } mopoe_buffers;
 
 typedef struct mopoe_adam {
@@ -265,14 +297,17 @@ int mopoe_train_step(const mopoe_model* model, const mopoe_step* step,
 
 /* Replaces torch.optim.Adam.step (experiment.py:256-279) on the flat buffer,
  * restricted to the segments of the modalities in present_mask (parameters
- * whose .grad is None are skipped by torch).  `grad_scale` multiplies the
- * gradient first (1/world_size after a sum all-reduce).  `step` is the Adam
- * step number t when the host knows it (bias corrections are then computed
- * on the host); pass 0 to have the kernel read t from buf->counters[0]
- * (what a captured graph needs). */
+ * whose .grad is None are skipped by torch; their step count does not advance).
+ * The step number of each modality's parameters lives on the device
+ * (counters[MOPOE_CTR_ADAM_STEPS + m]) -- a captured graph replays correctly.
+ * `world` > 1: buf->grads holds the SUM over `world` data-parallel ranks (after an
+ * all-reduce): the gradient is multiplied by 1/world first, and the ranks' batches
+ * are checked to have held the same modalities (the control words mopoe_train_step
+ * leaves behind the last segment of buf->grads travel through the same
+ * all-reduce); if not, nothing is updated and MOPOE_CTR_INVALID is raised. */
 int mopoe_adam_step(const mopoe_model* model, int32_t present_mask,
                     const mopoe_buffers* buf, const mopoe_adam* adam,
-                    float grad_scale, int32_t step, void* stream);
+                    int32_t world, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Data-parallel replicas on one node (the reference has no
@@ -317,7 +352,7 @@ int mopoe_comm_connect(mopoe_comm* comm, const void* handles);
 int mopoe_comm_allreduce(mopoe_comm* comm, float* data, void* stream);
 int mopoe_comm_allreduce_adam(mopoe_comm* comm, const mopoe_model* model,
                               int32_t present_mask, const mopoe_buffers* buf,
-                              const mopoe_adam* adam, int32_t step, void* stream);
+                              const mopoe_adam* adam, void* stream);
 int mopoe_comm_train_step(mopoe_comm* comm, const mopoe_model* model,
                           const mopoe_step* step, const mopoe_buffers* buf,
                           const mopoe_adam* adam, void* stream);
@@ -328,8 +363,7 @@ int mopoe_comm_destroy(mopoe_comm* comm);
 
 /* torch.nn.Linear (+ optional ReLU) as used by Encoder.forward / Decoder.forward
  * (multimodal_cohort/networks/networks.py:30-36,66-77):
- * y (n, ncols) = act(x (n, k) @ w (ncols, k)^T + b).  x as mopoe_buffers.x: readable
- * for 16 bytes past its last row. */
+ * y (n, ncols) = act(x (n, k) @ w (ncols, k)^T + b). */
 int mopoe_linear(const float* x, int32_t n, int32_t k, const float* w,
                  const float* b, int32_t ncols, int32_t relu, float* y,
                  void* stream);

@@ -63,7 +63,8 @@ def make_engine(cfg, device="cuda"):
                         beta_style=cfg.beta_style, beta_content=cfg.beta_content,
                         initial_out_logvar=cfg.initial_out_logvar,
                         learn_output_scale=cfg.learn_output_scale, lr=cfg.lr,
-                        betas=cfg.betas, adam_eps=cfg.adam_eps)
+                        betas=cfg.betas, adam_eps=cfg.adam_eps,
+                        poe_unimodal_elbos=cfg.poe_unimodal_elbos)
     eng = mm.MoPoEEngine(spec, device)
     eng.load_params(mo.init_params(cfg, 0))
     return spec, eng

@@ -20,9 +20,10 @@ def test_train_steps_match_oracle(case):
     spec, eng = make_engine(cfg)
     params = mo.init_params(cfg, 0)
     state = mo.adam_init(params)
-    x = fx.inputs()
     rep = Report(case)
+    adam_steps = OrderedDict((k, 0) for k in params)   # torch: one count per parameter
     for step in range(fx.steps):
+        x = fx.inputs_at(step)      # (mixed-mask cases: the batch's modalities change)
         noise = fx.noise(step)
         # the oracle steps from the HIP path's current parameters, so every
         # step is compared on identical weights
@@ -31,7 +32,7 @@ def test_train_steps_match_oracle(case):
                                spec.param_views(eng.exp_avg).items())
         v_before = OrderedDict((k, v.cpu().clone()) for k, v in
                                spec.param_views(eng.exp_avg_sq).items())
-        state = {"step": step, "exp_avg": m_before, "exp_avg_sq": v_before}
+        state = {"step": adam_steps, "exp_avg": m_before, "exp_avg_sq": v_before}
         out, grads = mo.train_step(params, cfg, x, noise, state)
         plan, ws = eng.train_step(x, eps=noise.tape)
         torch.cuda.synchronize()
@@ -62,6 +63,10 @@ def test_train_steps_match_oracle(case):
             rep.close(p + "rec/%s/scale" % k, res["rec"][k].scale[0],
                       (params["decoders.%s.logvar" % k][0] * 0.5).exp(), 1e-6, 1e-7)
         assert eng.step_count() == step + 1
+        # the device's per-modality Adam counts are torch's per-parameter ones
+        for name, t in eng.adam_steps().items():
+            assert t == adam_steps["encoders.%s.shared_encoder.0.weight" % name], (name, t)
+        eng.check_valid(sync=True)
     rep.finish()
 
 

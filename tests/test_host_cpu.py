@@ -142,20 +142,15 @@ def test_group_rows_sizes_the_row_position_rules_for_one_repeat():
         spec.plan(names, 2000, backward=True, group_rows=50)   # forward-only
 
 
-def test_input_matrices_get_readable_slack_after_the_last_row():
-    """include/mopoe_hip.h: x[m] must stay readable 16 bytes past its last row (the
-    kernels' 16-byte row loads cover the next row's start when d % 4 != 0).  The host
-    side guarantees it: a matrix that ends flush with its storage is copied into one
-    with slack, one that already qualifies is passed through untouched."""
+def test_input_matrices_are_passed_as_they_are():
+    """ABI 6: x[m] is read through a descriptor of exactly x_rows[m] * d_m floats, so the
+    caller owes no slack after the last row and the host side makes no copy of a matrix
+    that is already float32, contiguous and on the device."""
     L = mm._lib
+    assert not hasattr(L, "rows_with_slack")
     flush = torch.randn(256, 7)                       # storage ends with the last row
-    got = L.rows_with_slack(flush, "cpu")
-    assert torch.equal(got, flush) and got.data_ptr() != flush.data_ptr()
-    slack = got.untyped_storage().nbytes() - (got.storage_offset() + got.numel()) * 4
-    assert slack >= L.ROW_SLACK_BYTES
-    assert L.rows_with_slack(got, "cpu") is got       # qualifies now
-    wide = torch.randn(256, 444)                      # d % 4 == 0: no load crosses a row end
-    assert L.rows_with_slack(wide, "cpu") is wide
-    tail = torch.randn(300, 7)[:256]                  # a view with rows behind it
-    assert L.rows_with_slack(tail, "cpu") is tail
-    assert L.rows_with_slack(flush.double(), "cpu").dtype == torch.float32
+    assert L.device_rows(flush, "cpu") is flush
+    tail = torch.randn(300, 7)[:256]
+    assert L.device_rows(tail, "cpu") is tail
+    assert L.device_rows(flush.double(), "cpu").dtype == torch.float32
+    assert L.device_rows(torch.randn(7, 256).t(), "cpu").is_contiguous()

@@ -19,8 +19,8 @@ for it in range(60):
     plan, ws = eng.train_step(pool[it % 8]); torch.cuda.synchronize()
     c = eng.counters.cpu().view(torch.int32)
     s = ws._stats_all.cpu().view(torch.int32)
-    lat = s[64:64 + 32].view(16, 2)
-    rows.append([int(s[64 + 45])] + [int(c[16 + i]) for i in range(8)] + [int(s[64 + 47]), int(s[64 + 48]), int(lat[1, 0])])
+    lat = s[128:128 + 32].view(16, 2)
+    rows.append([int(s[128 + 45])] + [int(c[64 + 16 + i]) for i in range(8)] + [int(s[128 + 47]), int(s[128 + 48]), int(lat[1, 0])])
 r = np.array(rows, dtype=np.int64) & 0xFFFFFFFF
 rel = ((r - r[:, :1] + (1 << 31)) % (1 << 32) - (1 << 31)) / 100.0
 med = np.median(rel, axis=0)

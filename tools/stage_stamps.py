@@ -31,7 +31,7 @@ acc = None
 for it in range(40):
     plan, ws = eng.train_step(pool[it % 8])
     torch.cuda.synchronize()
-    raw = ws._stats_all[64:64 + 30].cpu().view(torch.int32).view(15, 2).double()
+    raw = ws._stats_all[128:128 + 30].cpu().view(torch.int32).view(15, 2).double()
     st = raw[used]
     d = (st[1:] - st[:-1]) % 4294967296.0
     acc = d if acc is None else acc + d

@@ -23,10 +23,10 @@ for it in range(60):
     plan, ws = eng.train_step(pool[it % 8]); torch.cuda.synchronize()
     c = eng.counters.cpu().view(torch.int32)
     s = ws._stats_all.cpu().view(torch.int32)
-    lat = s[64:64 + 32].view(16, 2)
-    cur = [int(c[11]), int(c[13]), int(c[14]), int(c[15]), int(c[12]), int(s[64 + 45]), int(lat[0, 0]), int(lat[10, 0]), int(s[64 + 46]),
-           int(s[64 + 40]), int(s[64 + 41]), int(s[64 + 42]), int(s[64 + 43]), int(s[64 + 44]),
-           int(s[64 + 60]), int(s[64 + 61]), int(s[64 + 62]), int(s[64 + 63])]
+    lat = s[128:128 + 32].view(16, 2)
+    cur = [int(c[64 + 11]), int(c[64 + 13]), int(c[64 + 14]), int(c[64 + 15]), int(c[64 + 12]), int(s[128 + 45]), int(lat[0, 0]), int(lat[10, 0]), int(s[128 + 46]),
+           int(s[128 + 40]), int(s[128 + 41]), int(s[128 + 42]), int(s[128 + 43]), int(s[128 + 44]),
+           int(s[128 + 60]), int(s[128 + 61]), int(s[128 + 62]), int(s[128 + 63])]
     rows.append(cur)
 import numpy as np
 r = np.array(rows, dtype=np.int64) & 0xFFFFFFFF
