@@ -1609,12 +1609,12 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s) 
 // MOPOE_FUSE_BLOCKS caps the grid the fused launch is used for.  Read per call (two
 // getenv), so a test can compare the two forms inside one process.
 static bool no_fuse() { return getenv("MOPOE_NO_FUSE") != nullptr; }
-// MOPOE_TEST_HANDOFF_SPINS: a test knob -- with 1 a row group gives up at its first poll, which
-// is how tests/test_hip_invalid.py drives the "step could not be completed" path.
+// MOPOE_TEST_HANDOFF_SPINS: a test knob -- with 0 every row group of the fused launch gives
+// up without looking at its flag, which is how tests/test_hip_invalid.py drives the "step
+// could not be completed" path (flags left non-zero by the producers included).
 static int handoff_spins() {
     const char* v = getenv("MOPOE_TEST_HANDOFF_SPINS");
-    const int n = v ? atoi(v) : kHandoffSpins;
-    return n > 0 ? n : kHandoffSpins;
+    return v ? atoi(v) : kHandoffSpins;
 }
 static int fuse_blocks() {
     const char* v = getenv("MOPOE_FUSE_BLOCKS");

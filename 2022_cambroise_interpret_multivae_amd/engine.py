@@ -389,6 +389,34 @@ class MoPoEEngine:
         res["rec"] = rec
         return res
 
+    def log_scalars(self, plan, stats):
+        """The scalar set the reference's TBLogger writes per step
+        (utils/TBLogger.py:84-96: Loss, LogProb/<modality>, KLD/<subset>,
+        group_divergence, mu/<latent>, logvar/<latent>) as plain floats, from ONE copy
+        of the step's stats vector -- `stats` is ws.stats or the pinned host tensor the
+        kernels wrote (`stats_host`); reading it costs no further synchronisation
+        than the caller already paid."""
+        v = stats.tolist() if hasattr(stats, "tolist") else list(stats)
+        spec = self.spec
+        out = OrderedDict()
+        out["Loss"] = {"loss": v[L.STAT_TOTAL_LOSS]}
+        out["LogProb"] = OrderedDict(
+            (spec.names[m], v[L.STAT_NLL + j]) for j, (m, slot, src, pas) in
+            enumerate(plan.jobs) if pas == 0)
+        out["KLD"] = OrderedDict((key, v[L.STAT_KLD_SUBSET + s])
+                                 for key, s in zip(plan.avail_keys, plan.avail_idx))
+        out["group_divergence"] = {"group_div": v[L.STAT_JOINT_DIV]}
+        mu, logvar = OrderedDict(), OrderedDict()
+        for m, name in enumerate(spec.names):       # latents['modalities'] order
+            if name not in plan.present:
+                continue
+            base = L.STAT_LATENT_MEAN + 4 * m
+            if spec.has_style(m):
+                mu[name + "_style"], logvar[name + "_style"] = v[base], v[base + 1]
+            mu[name], logvar[name] = v[base + 2], v[base + 3]
+        out["mu"], out["logvar"] = mu, logvar
+        return out
+
     def scalars(self, plan, ws):
         """log_probs / klds / total_loss of run_epochs.basic_routine_epoch
         (run_epochs.py:89-135) as 0-dim views of the stats buffer."""

@@ -187,6 +187,25 @@ class MissingModalitySampler(torch.utils.data.Sampler):
         return iter(mine)
 
 
+def fit_scalers(dataset):
+    """{mod: (mean, scale)} of the per-modality StandardScaler the reference fits on the
+    training set (experiment.py:146-166: every sample that has the modality, through the
+    dataset's __getitem__; population standard deviation, a constant feature keeps
+    scale 1) -- float64, straight from the blocks: a block row belongs to exactly one
+    subject, so the rows the dataset's subjects point at are the fitted samples."""
+    out = {}
+    subjects = np.arange(dataset.n_samples) if dataset.indices is None \
+        else np.asarray(dataset.indices)
+    for mod in dataset.modalities:
+        rows = [int(r) for r in dataset.idx_per_mod[mod][subjects] if r is not None]
+        x = np.asarray(dataset.data[mod], dtype=np.float64)[rows]
+        mean = x.mean(axis=0)
+        scale = np.sqrt(((x - mean) ** 2).mean(axis=0))
+        scale[scale < 10 * np.finfo(np.float64).eps * np.maximum(1.0, np.abs(mean))] = 1.0
+        out[mod] = (mean, scale)
+    return out
+
+
 class ResidentCohort:
     """Per-modality blocks, scaled once and resident in HBM; batches are index
     vectors.  `scalers` = {mod: (mean, scale)} reproduces the per-sample

@@ -335,12 +335,76 @@ def sampler_vectors(ns):
     return store
 
 
+def scaler_vectors(ns):
+    """The input scaling of the reference on a synthetic cohort: the StandardScaler its
+    MultimodalExperiment.set_scalers fits (experiment.py:146-166) and what its
+    per-sample on-the-fly transform chain delivers (experiment.py:228-232:
+    unsqueeze(0) -> scaler.transform -> ToTensor -> squeeze), cast as the training
+    loop casts it (run_epochs.py:86, .float())."""
+    import importlib
+    import types
+    ref_exp = importlib.import_module("multimodal_cohort.experiment")
+    tv = sys.modules["torchvision.transforms"]
+
+    class Compose:      # the two torchvision transforms the chain uses, on tensors/arrays
+        def __init__(self, fns):
+            self.fns = fns
+
+        def __call__(self, v):
+            for f in self.fns:
+                v = f(v)
+            return v
+
+    class ToTensor:
+        def __call__(self, a):       # (H, W) ndarray -> (1, H, W) tensor
+            return torch.from_numpy(np.asarray(a))[None]
+
+    tv.Compose, tv.ToTensor = Compose, ToTensor
+    rng = np.random.RandomState(11)
+    n = 60
+    has = {"clinical": rng.rand(n) > 0.2, "rois": rng.rand(n) > 0.25}
+    has["clinical"] |= ~has["rois"]
+    dims = {"clinical": 7, "rois": 12}
+    data, idx = {}, {}
+    for mod in ("clinical", "rois"):
+        rows = np.flatnonzero(has[mod])
+        data[mod] = rng.randn(len(rows), dims[mod]) * rng.uniform(0.5, 40.0, dims[mod]) + \
+            rng.uniform(-30.0, 30.0, dims[mod])
+        perm = rng.permutation(len(rows))
+        col = np.empty(n, dtype=object)
+        col[:] = None
+        for k, subj in enumerate(rows):
+            col[subj] = int(perm[k])
+        idx[mod] = col
+    data["clinical"][:, 3] = 2.5          # a constant feature: scale stays 1
+    samples = []                          # what the reference's dataset[i] returns
+    for i in range(n):
+        samples.append(({mod: torch.tensor(data[mod][idx[mod][i]]) for mod in dims
+                         if idx[mod][i] is not None}, 0, {}))
+    fake = types.SimpleNamespace(mod_names=["clinical", "rois"])
+    scalers = ref_exp.MultimodalExperiment.set_scalers(fake, samples)
+    store = OrderedDict()
+    for mod in dims:
+        store["data/" + mod] = data[mod]
+        store["idx/" + mod] = np.array([-1 if r is None else r for r in idx[mod]], dtype=np.int64)
+        store["mean/" + mod] = scalers[mod].mean_
+        store["scale/" + mod] = scalers[mod].scale_
+        chain = tv.Compose([lambda x: x.unsqueeze(0), scalers[mod].transform, tv.ToTensor(),
+                            torch.squeeze])
+        rows = [chain(s[0][mod]).float().numpy() for s in samples if mod in s[0]]
+        store["transformed/" + mod] = np.stack(rows)      # subjects that have it, in order
+    return store
+
+
 def main():
     ns = rh.import_reference()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     total = 0
     only = sys.argv[1:]            # optional: case names to (re)generate
     if only:
+        if "scaler" in only:
+            np.savez_compressed(os.path.join(GOLDEN_DIR, "scaler.npz"), **scaler_vectors(ns))
+            print("scaler.npz written")
         for c in CASES:
             if c["case"] in only:
                 store = run_case(ns, c)
@@ -368,6 +432,10 @@ def main():
     total += os.path.getsize(path)
     store = sampler_vectors(ns)
     path = os.path.join(GOLDEN_DIR, "sampler.npz")
+    np.savez_compressed(path, **store)
+    total += os.path.getsize(path)
+    store = scaler_vectors(ns)
+    path = os.path.join(GOLDEN_DIR, "scaler.npz")
     np.savez_compressed(path, **store)
     total += os.path.getsize(path)
     print("total %d B" % total)

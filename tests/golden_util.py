@@ -17,7 +17,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def case_names(prefix=None, fwd=False):
     names = sorted(os.path.basename(p)[:-4]
                    for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    names = [n for n in names if n not in ("l0_functions", "sampler")]
+    names = [n for n in names if n not in ("l0_functions", "sampler", "scaler")]
     names = [n for n in names if n.startswith("fwd_") == fwd]
     if prefix:
         names = [n for n in names if n.startswith(prefix)]

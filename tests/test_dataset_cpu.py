@@ -61,3 +61,30 @@ def test_dataset_items_and_stratify_refusal():
     assert abs(sum(ds.get_modality_proportions()) - 1.0) < 1e-12
     with pytest.raises(NotImplementedError):
         ds_mod.MissingModalitySampler(ds, 8, stratify=["age"])
+
+
+def test_scaler_reproduces_the_reference_transform_chain():
+    """tests/golden/scaler.npz: the StandardScaler the reference's set_scalers fits
+    (experiment.py:146-166) and the rows its per-sample transform chain delivers
+    (experiment.py:228-232), recorded from the reference.  fit_scalers + ResidentCohort
+    scale each block once, in float64, and round to float32 as the loop's .float() does."""
+    z = np.load(GOLDEN_DIR + "/scaler.npz", allow_pickle=False)
+    data, idx = {}, {}
+    for mod in ("clinical", "rois"):
+        data[mod] = z["data/" + mod]
+        col = np.empty(len(z["idx/" + mod]), dtype=object)
+        col[:] = [None if r < 0 else int(r) for r in z["idx/" + mod]]
+        idx[mod] = col
+    ds = ds_mod.MultimodalDataset(data, idx)
+    scalers = ds_mod.fit_scalers(ds)
+    for mod in ds.modalities:
+        assert np.allclose(scalers[mod][0], z["mean/" + mod], rtol=1e-12, atol=1e-12)
+        assert np.allclose(scalers[mod][1], z["scale/" + mod], rtol=1e-12, atol=1e-12)
+    assert scalers["clinical"][1][3] == 1.0            # the constant feature
+    cohort = ds_mod.ResidentCohort(ds, "cpu", scalers=scalers)
+    for mod in ds.modalities:
+        rows = [int(r) for r in z["idx/" + mod] if r >= 0]     # subjects that have it, in order
+        got = cohort.x[mod][rows].numpy()
+        want = z["transformed/" + mod]
+        assert got.dtype == want.dtype == np.float32
+        assert np.allclose(got, want, rtol=2e-7, atol=1e-7), np.abs(got - want).max()

@@ -1,6 +1,9 @@
-"""GPU: index batches over HBM-resident blocks (row_index of the C ABI) give
-bit-identical steps to materialised batches; the scaler matches
-sklearn.preprocessing.StandardScaler; a full sampler epoch of run_epochs.train."""
+"""GPU, SURVEY.md section 8f row f1: index batches over HBM-resident blocks (row_index
+of the C ABI).  Every batch of a MissingModalitySampler epoch is checked against the
+ORACLE run on the gathered, scaled rows (loss terms, posteriors, gradients), and
+against the materialised-batch HIP path bit for bit; the scaler is the reference's
+StandardScaler (tests/golden/scaler.npz pins the CPU side); a full sampler epoch of
+run_epochs.train."""
 from collections import OrderedDict
 from importlib import import_module
 
@@ -9,7 +12,7 @@ import pytest
 import torch
 
 import mopoe_oracle as mo
-from hip_util import make_engine
+from hip_util import Report, TOL, compare_forward, make_engine
 from surface_util import make_experiment, run_epochs
 
 pytestmark = pytest.mark.gpu
@@ -50,15 +53,27 @@ def test_index_batches_equal_materialised_batches():
     np.random.seed(4)
     batches = list(ds_mod.MissingModalitySampler(ds, 48))
     seen = set()
-    for b in batches:
+    spec = eng_a.spec
+    rep = Report("gather batches vs oracle")
+    for k, b in enumerate(batches):
         inputs, row_index = cohort.batch(b)
         seen.add(tuple(inputs))
         gathered = OrderedDict((m, cohort.x[m][row_index[m].long().cuda()]) for m in inputs)
-        eng_a.seed = eng_b.seed = 99
-        _, ws_a = eng_a.train_step(inputs, row_index=row_index)
-        _, ws_b = eng_b.train_step(gathered)
+        # the oracle on the rows the reference's per-sample transform would deliver
+        x_o = OrderedDict((m, torch.from_numpy(scaled[m][row_index[m].numpy()]))
+                          for m in inputs)
+        params = OrderedDict((n, v.cpu()) for n, v in eng_a.named_params().items())
+        noise = mo.Noise(generator=mo.noise_rng(300 + k))
+        out, grads = mo.loss_and_grads(params, cfg, x_o, noise)
+        plan, ws_a = eng_a.train_step(inputs, row_index=row_index, eps=noise.tape)
+        _, ws_b = eng_b.train_step(gathered, eps=noise.tape)
         torch.cuda.synchronize()
         assert torch.equal(ws_a.stats, ws_b.stats)
+        p = "batch%d/" % k
+        compare_forward(rep, spec, eng_a, plan, ws_a, out, prefix=p, check_scale=False)
+        for n, g in grads.items():
+            rep.close_scaled(p + "grad/" + n, eng_a.grad_views[n], g, TOL["grad"])
+    rep.finish()
     assert torch.equal(eng_a.params, eng_b.params)            # bit-identical training
     assert seen == {("clinical",), ("rois",), ("clinical", "rois")}
 

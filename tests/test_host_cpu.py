@@ -154,3 +154,31 @@ def test_input_matrices_are_passed_as_they_are():
     assert L.device_rows(tail, "cpu") is tail
     assert L.device_rows(flush.double(), "cpu").dtype == torch.float32
     assert L.device_rows(torch.randn(7, 256).t(), "cpu").is_contiguous()
+
+
+def test_hot_kernels_keep_their_registers_and_scratch():
+    """The step's speed rests on compiler settings (csrc/Makefile: -Os, iterative-ILP
+    scheduler) whose effect is visible in the per-kernel resource report the build
+    keeps next to the library: any sizeable private segment cost 3x on MI355X, and a
+    1024-thread workgroup cannot hold more than 128 VGPRs per lane.  A toolchain
+    change that moves these fails here instead of silently costing microseconds."""
+    path = os.path.join(os.path.dirname(L.LIB_PATH), "csrc", "resources.txt")
+    assert os.path.exists(path), "build with make -C .../csrc (it writes resources.txt)"
+    assert os.path.getmtime(path) >= os.path.getmtime(L.LIB_PATH) - 120
+    text = open(path).read()
+    kernels = {}
+    for block in text.split("Function Name: ")[1:]:
+        name = block.split()[0]
+        get = lambda key: int(re.search(re.escape(key) + r": (\d+)", block).group(1))
+        kernels[name] = dict(vgpr=get("VGPRs"), scratch=get("ScratchSize [bytes/lane]"),
+                             sgpr_spill=get("SGPRs Spill"), occupancy=get("Occupancy [waves/SIMD]"))
+    pick = lambda frag: next(v for k, v in kernels.items() if frag in k)
+    lean, generic = pick("k_fusedILb1EE"), pick("k_fusedILb0EE")
+    latent, linear = pick("k_latentE"), pick("8k_linearE")
+    assert lean["vgpr"] <= 128 and lean["scratch"] <= 76 and lean["occupancy"] >= 4, lean
+    assert generic["vgpr"] <= 128 and generic["scratch"] <= 128, generic
+    assert latent["vgpr"] <= 128 and latent["scratch"] == 0, latent
+    assert linear["scratch"] == 0, linear
+    for frag in ("k_wgradILi4ELb0", "k_wgradILi8ELb0", "k_wgradILi4ELb1", "k_wgradILi8ELb1",
+                 "k_adamE", "k_xgmiE", "k_linear_bigE"):
+        assert pick(frag)["scratch"] == 0, (frag, pick(frag))
