@@ -191,18 +191,32 @@ DEV AdamCoef adam_coef_of(const mopoe_adam& ad, double bc1, float bc2_sqrt) {
 }
 
 // First kernel of a training step, ONE thread: the step number, and (when the step
-// applies Adam) records that are valid for it.
+// applies Adam) records that are valid for it.  Everything is read before anything is
+// written: a store to the same buffer in between would order the loads behind it, one
+// memory round trip each.
 DEV void step_begin(int32_t* counters, int num_mods, const mopoe_adam* ad) {
-    const int s = counters[MOPOE_CTR_STEPS_BEGUN] + 1;
+    const int c0 = counters[MOPOE_CTR_STEPS_BEGUN];
+    const int cb1 = counters[kCtrBeta], cb2 = counters[kCtrBeta + 1];
+    int tag0[MOPOE_MAX_MODS], tag1[MOPOE_MAX_MODS], steps[MOPOE_MAX_MODS];
+#pragma unroll
+    for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
+        tag0[m] = counters[MOPOE_CTR_BIAS + m * 4 + 3];
+        tag1[m] = counters[MOPOE_CTR_BIAS + (MOPOE_MAX_MODS + m) * 4 + 3];
+        steps[m] = counters[MOPOE_CTR_ADAM_STEPS + m];
+    }
+    const int s = c0 + 1;
     counters[MOPOE_CTR_STEPS_BEGUN] = s;
     if (!ad) return;
-    const bool same = betas_match(counters, *ad);
-    for (int m = 0; m < num_mods; ++m) {
-        BiasRec* r = bias_rec(counters, s, m);
-        if (!same || r->tag != s) *r = bias_of(*ad, counters[MOPOE_CTR_ADAM_STEPS + m] + 1, s);
+    const int ab1 = __builtin_bit_cast(int32_t, ad->beta1), ab2 = __builtin_bit_cast(int32_t, ad->beta2);
+    const bool same = cb1 == ab1 && cb2 == ab2;
+#pragma unroll
+    for (int m = 0; m < MOPOE_MAX_MODS; ++m)
+        if (m < num_mods && (!same || ((s & 1) ? tag1[m] : tag0[m]) != s))
+            *bias_rec(counters, s, m) = bias_of(*ad, steps[m] + 1, s);
+    if (!same) {
+        counters[kCtrBeta] = ab1;
+        counters[kCtrBeta + 1] = ab2;
     }
-    counters[kCtrBeta] = __builtin_bit_cast(int32_t, ad->beta1);
-    counters[kCtrBeta + 1] = __builtin_bit_cast(int32_t, ad->beta2);
 }
 
 // Last block of the kernel that applied (or, on an invalid step, withheld) the Adam
