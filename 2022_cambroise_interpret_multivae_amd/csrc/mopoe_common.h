@@ -155,6 +155,10 @@ struct LatentLds {
     uint32_t joint_jobs;               // decoder jobs fed by the joint latent
     DecJob dj[MOPOE_MAX_JOBS];
     EncMod em[MOPOE_MAX_MODS];
+    // LDS tiles whose K padding the GEMM stages read (z, g_heads): zeroed whole, first
+    // thing, one 16-byte store per thread (prefix table in float4 units)
+    int zr_begin[MOPOE_MAX_JOBS + MOPOE_MAX_MODS + 1];
+    int zr_off[MOPOE_MAX_JOBS + MOPOE_MAX_MODS];
     int rows;                          // batch rows a group owns (16, 8, 4, 2 or 1)
     int rd;                            // round_up(rows * class_dim, 4): stride of a KL-term slab
     int fits;                          // the carve-up fits the 160 KiB budget
@@ -415,6 +419,20 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
         f.hidden = nullptr;
         f.heads_out = f.g_pre = f.g_heads = nullptr;
         for (int k = 0; k < 12; ++k) f.pad[k] = 0;
+    }
+    {
+        int k = 0, q = 0;
+        for (int j = 0; j < MOPOE_MAX_JOBS; ++j) {
+            L.zr_begin[k] = q;
+            L.zr_off[k++] = L.zj[j < st.num_jobs ? j : 0];
+            if (j < st.num_jobs) q += R * ld_z_lds(m, st.job_mod[j]) / 4;
+        }
+        for (int i = 0; i < MOPOE_MAX_MODS; ++i) {
+            L.zr_begin[k] = q;
+            L.zr_off[k++] = L.gheads[i];
+            if (i < m.num_mods && ((st.present_mask >> i) & 1)) q += R * ld_heads_lds(m, i) / 4;
+        }
+        L.zr_begin[k] = q;
     }
     if (st.joint_mode == MOPOE_JOINT_EXPERT) {
         L.fs[st.expert_subset].hi = 0x7fffffff;
@@ -698,10 +716,12 @@ DEV f32x4 glb_b4_nt(rsrc_t r, int ldw, int K, int j0, int kb, int lane) {
     return v;
 }
 
-// Philox4x32-10 -> one standard normal (Box-Muller).  Counter = (element,
-// stream, step, tag), key = seed.
-DEV float philox_normal(uint64_t seed, uint32_t step, uint32_t stream, uint32_t idx) {
-    uint32_t c0 = idx, c1 = stream, c2 = step, c3 = 0x4d6f506fu;
+// Philox4x32-10 -> FOUR standard normals per call (two Box-Muller pairs; the angle goes
+// through v_sin_f32 / v_cos_f32, which take revolutions: no range reduction).  Counter =
+// (quad, stream, step, tag), key = seed; element idx of a stream is component idx & 3 of
+// quad idx >> 2, so a lane that owns four consecutive elements pays for one call.
+DEV f32x4 philox_normal4(uint64_t seed, uint32_t step, uint32_t stream, uint32_t quad) {
+    uint32_t c0 = quad, c1 = stream, c2 = step, c3 = 0x4d6f506fu;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -716,9 +736,24 @@ DEV float philox_normal(uint64_t seed, uint32_t step, uint32_t stream, uint32_t 
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
-    const float u1 = ((c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
-    const float u2 = ((c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    const float u0 = ((c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+    const float u1 = ((c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((c2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u3 = ((c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    // sqrt(-2 ln u) = sqrt(-2 ln2 * log2 u)
+    const float ra = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u0));
+    const float rb = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u2));
+    f32x4 v;
+    v[0] = ra * __builtin_amdgcn_cosf(u1);
+    v[1] = ra * __builtin_amdgcn_sinf(u1);
+    v[2] = rb * __builtin_amdgcn_cosf(u3);
+    v[3] = rb * __builtin_amdgcn_sinf(u3);
+    return v;
+}
+DEV float philox_normal(uint64_t seed, uint32_t step, uint32_t stream, uint32_t idx) {
+    const f32x4 v = philox_normal4(seed, step, stream, idx >> 2);
+    const uint32_t k = idx & 3u;
+    return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : v[3];
 }
 
 #endif  // __HIPCC__

@@ -98,7 +98,7 @@ struct KArgs {
     mopoe_buffers buf;
     LatentLds lds;  // carve-up of k_latent's LDS, computed on the host
 };
-static_assert(sizeof(KArgs) <= 7680, "kernel argument block too large");  // (12 KB launches fine: tools/kernarg_probe.hip)
+static_assert(sizeof(KArgs) <= 7680 + 512, "kernel argument block too large");  // (12 KB launches fine: tools/kernarg_probe.hip)
 
 DEV int src_row(const mopoe_buffers& buf, int m, int gn) {
     return buf.row_index[m] ? buf.row_index[m][gn] : gn;
@@ -135,6 +135,7 @@ struct LinArgs {
     int32_t ksplit;        // 1, 2 or 4: K parts per column tile (set by launch_linear)
     int32_t num_mods;      // modalities of the model (the Adam records of step_begin)
     int32_t spins;         // fused launch: polls of a row group before it gives up
+    int32_t knock;         // (diagnostic build -DMOPOE_KNOCK: phases to leave out)
     mopoe_adam adam;
     LinGroup g[MOPOE_MAX_MODS];
 };
@@ -579,28 +580,50 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a_by_value) {
 // flag.  Producers never wait for anything and sit at the LOW block indices, so the
 // wait of a consumer cannot deadlock whatever the residency (and it is bounded).
 // ---------------------------------------------------------------------------
-struct FArgs {
-    KArgs ka;      // first: latent_body prefetches sizeof(KArgs) bytes of the segment
-    LinArgs la;
+// What a block needs to find its work sits in the FIRST 64-byte line of the argument
+// block: one scalar-cache miss, not a chain of them, stands between a producer's entry
+// and its first load.
+struct alignas(64) FHead {
     int32_t nlin;        // encoder-layer blocks
     int32_t row_tiles;   // 16-row tiles = row groups
-    int32_t ks;          // 4: 64-column encoder tiles (K over four waves); 1: 256-column ones
+    int32_t ks;          // 4: K over four waves per column tile; 1: a wave per column tile
+    int32_t producers;   // encoder-layer blocks per row tile (what a row group waits for)
+    int32_t begin[MOPOE_MAX_MODS + 1];  // first block of encoder group z
+    int32_t tiles[MOPOE_MAX_MODS];      // 16-column tiles per block of group z (ks == 4: 4 or 2)
+    int32_t pad;
+};
+static_assert(sizeof(FHead) == 64, "one scalar cache line");
+struct FArgs {
+    FHead hd;
+    KArgs ka;
+    LinArgs la;
 };
 
 // KS = 4: 64 columns per block, K over four waves (few row tiles); KS = 1: 256 columns
 // per block, a wave per column tile (more row tiles than the grid could hold otherwise)
-template <int KS>
+// A block's MFMA time is its column tiles x K: with 64 columns of a 444-wide modality a
+// CU issues 444 MFMAs (1.5 us) while the blocks of a 7-wide one issue 8 -- so a wide
+// modality gets blocks of kTiles = 2 tiles (32 columns): twice the blocks, half the
+// chain, same K parts and the same summation order (the waves beyond KS * kTiles only
+// help staging the x tile).
+template <int KS, int kTiles = kLatentWaves / KS>
 DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt, int cg,
                         int tid, int lane, int wave, int32_t* flag, int slot) {
-    constexpr int CH = 8, kStage = 2, kTiles = kLatentWaves / KS, kCols = 16 * kTiles;
+    constexpr int CH = 8, kStage = 2, kCols = 16 * kTiles;
+    static_assert(KS * kTiles <= kLatentWaves, "a wave per (tile, K part)");
     const int N = a.n, K = g.K;
     const bool vec = K % 4 == 0 || g.wslack;   // W: 4-wide reads stay inside the buffer
     const int n0 = rt * kRows;
-    const int tile = wave / KS, part = wave % KS;
+    const bool busy = wave < KS * kTiles;      // (wave-uniform)
+    const int tile = busy ? wave / KS : 0, part = wave % KS;
     const int j0 = (cg * kTiles + tile) * 16;
     int* rowsel = reinterpret_cast<int*>(lds);
     float* xt = lds + kRows;
     const bool gather = g.rows != nullptr;
+    // (diagnostic build: the phases of one producer of the wide modality, row tile 0)
+    const bool pstamp = a.counters && rt == 0 && cg == 0 && slot == a.ngroups - 1 && tid == 0;
+    (void)pstamp;
+    GSTAMP(a.counters, kCtrStamp + 32, pstamp);
     if (gather) {
         if (tid < kRows) rowsel[tid] = g.rows[min(n0 + tid, N - 1)];
         __syncthreads();
@@ -611,9 +634,10 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
         const int Kc = min(kEncKChunk, K - kc0);
         const int Kp = round_up(Kc, 16);
         const int ldx = Kp + 4;
-        const int kend = j0 < g.ncols ? Kp : 0;
+        const int kend = (busy & (j0 < g.ncols)) ? Kp : 0;
         const rsrc_t wr = make_rsrc(g.W + kc0, ((size_t)g.ncols * K + (g.wslack ? 3 : 0)) * sizeof(float));
         auto load_w = [&](int i0, f32x4 (&b)[CH]) __attribute__((always_inline)) {
+            if (!busy) return;
             if (vec) {
 #pragma unroll
                 for (int c = 0; c < CH; ++c)  // k >= Kc is out of range -> 0
@@ -642,6 +666,7 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
                 v[i] = ldg4_row(xr, base, rv, k, Kc);
             }
             load_w(0, b);  // behind the x loads (loads return in order)
+            GSTAMP(a.counters, kCtrStamp + 33, pstamp);
 #pragma unroll
             for (int i = 0; i < kStage; ++i) {
                 const int k = (i * kWave + lane) * 4;
@@ -649,6 +674,7 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
             }
         }
         __syncthreads();
+        GSTAMP(a.counters, kCtrStamp + 34, pstamp);
         for (int i0 = 0; 16 * (part + KS * i0) < kend; i0 += CH) {
             f32x4 bn[CH];
             const bool more = 16 * (part + KS * (i0 + CH)) < kend;  // wave-uniform
@@ -673,19 +699,31 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
         }
     }
     acc += acc2;
+    GSTAMP(a.counters, kCtrStamp + 35, pstamp);
+    // the bias of the four output columns this thread finishes: requested here, behind the
+    // MFMAs (their registers are free now) and ahead of the partial tiles' trip through
+    // LDS -- a load at the point of use would put a memory round trip in front of the
+    // hand-off
+    f32x4 bias4;
+    {
+        const int fcol = cg * kCols + (tid % (kCols / 4)) * 4;
+        const rsrc_t br = make_rsrc(g.b, g.b ? (size_t)g.ncols * sizeof(float) : 0);
+        bias4 = ldg4(br, guard((uint32_t)fcol * 4u, (tid < kRows * kCols / 4) & (fcol < g.ncols)));
+    }
     // All four K parts park their partial tiles in LDS as [row][column] (behind the x
     // tile); 256 threads then add the parts in fixed order, four consecutive columns
     // each, and write h with ONE 16-byte write-through store (the consumer group reads
     // it from memory; 4-byte write-through stores cost several times more per byte).
     constexpr int kLdR = kCols + 4;
     float* red = xt + kRows * (round_up(min(K, kEncKChunk), 16) + 4);
-    {
+    if (busy) {
         const int c16 = lane & 15, q = lane >> 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             red[(part * kRows + 4 * q + r) * kLdR + 16 * tile + c16] = acc[r];
     }
     __syncthreads();
+    GSTAMP(a.counters, kCtrStamp + 36, pstamp);
     if (tid < kRows * kCols / 4) {
         const int row = tid / (kCols / 4), c4 = (tid % (kCols / 4)) * 4;
         f32x4 v = *reinterpret_cast<const f32x4*>(red + row * kLdR + c4);
@@ -694,7 +732,7 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
             v += *reinterpret_cast<const f32x4*>(red + (p * kRows + row) * kLdR + c4);
         const int col = cg * kCols + c4, gn = n0 + row;
         if (col < g.ncols && gn < N) {   // (ncols is a multiple of 4 here: 256)
-            if (g.b) v += *reinterpret_cast<const f32x4*>(g.b + col);
+            v += bias4;   // (zeros without a bias)
             if (g.relu) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -708,8 +746,10 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
     GSTAMP(a.counters, kCtrStamp + 16 + slot * 4 + cg, a.counters && rt == 0 && tid == 0);
     // hand-off: every storing wave drains its stores, then ONE lane signals
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GSTAMP(a.counters, kCtrStamp + 37, pstamp);
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    GSTAMP(a.counters, kCtrStamp + 38, pstamp);
 }
 
 template <bool LEAN>
@@ -718,27 +758,51 @@ __global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value
     const FArgs& f = *(const FArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x;
-    const int stride = f.ka.lds.part_stride;
-    if (b < f.nlin) {
+    const FHead& hd = f.hd;   // (read in place: one scalar-cache line)
+    // the lines of the encoder layer's argument block, requested together with the head
+    // line: a producer's group record is then a scalar-cache hit, not a second miss
+    uint32_t karg_sink = 0;
+    {
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        for (int line = w; line < (int)(sizeof(LinArgs) / 64); line += kLatentWaves)
+            karg_sink |= ((const uint32_t*)&f.la)[line * 16];
+    }
+    if (b < hd.nlin) {
+#ifdef MOPOE_KNOCK
+        if ((f.la.knock >> 14) & 1) return;   // (diagnostic: producers leave at once)
+#endif
         const int tid = threadIdx.x, lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const LinArgs& a = f.la;
         // (the step number and the Adam records are looked after by row group 0 while it
         //  waits for its producers: step_begin has no business on a producer's path)
-        if (f.ks == 4) {
-            const int cg = b & 3, rt = (b >> 2) % f.row_tiles, z = (b >> 2) / f.row_tiles;
+        const int z = find_seg<MOPOE_MAX_MODS>(hd.begin, b);
+        const int local = b - hd.begin[z];
+        const int stride = f.ka.lds.part_stride;
+        if (hd.ks == 4) {
+            const int two = hd.tiles[z] == 2;
+            const int ncg = two ? 8 : 4;
+            const int cg = local % ncg, rt = local / ncg;
             int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * stride + kHandoffWord);
-            linear_block16<4>(a, a.g[z], lds, rt, cg, tid, lane, wave, flag, z);
+            if (two)
+                linear_block16<4, 2>(a, a.g[z], lds, rt, cg, tid, lane, wave, flag, z);
+            else
+                linear_block16<4, 4>(a, a.g[z], lds, rt, cg, tid, lane, wave, flag, z);
         } else {
-            const int rt = b % f.row_tiles, z = b / f.row_tiles;
+            const int rt = local;
             int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * stride + kHandoffWord);
             linear_block16<1>(a, a.g[z], lds, rt, 0, tid, lane, wave, flag, z);
         }
+        asm volatile("" ::"s"(karg_sink));
         return;
     }
-    const int grp = b - f.nlin;
-    int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)grp * stride + kHandoffWord);
-    latent_body<true, LEAN>(f.ka, lds, grp, flag, f.ks * f.la.ngroups, &f.la);
+    asm volatile("" ::"s"(karg_sink));
+#ifdef MOPOE_KNOCK
+    if ((f.la.knock >> 15) & 1) return;       // (diagnostic: row groups leave at once)
+#endif
+    const int grp = b - hd.nlin;
+    int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)grp * f.ka.lds.part_stride + kHandoffWord);
+    latent_body<true, LEAN>(f.ka, lds, grp, flag, hd.producers, &f.la);
 }
 
 // Scalars of the step from the row tiles' partial sums, in a fixed order
@@ -1644,6 +1708,9 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     la.publish = adam != nullptr;
     la.num_mods = mdl.num_mods;
     la.spins = handoff_spins();
+#ifdef MOPOE_KNOCK
+    la.knock = getenv("MOPOE_KNOCK") ? (int)strtol(getenv("MOPOE_KNOCK"), nullptr, 0) : 0;
+#endif
     if (adam) la.adam = *adam;
     int maxd = 1;
     for (int m = 0; m < mdl.num_mods; ++m) {
@@ -1670,15 +1737,46 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     // Small training batches: encoder layer and per-sample chain in ONE launch
     // (k_fused).  Needs full 16-row groups and the whole grid resident at once to pay.
     const int row_tiles = cdiv(ka.st.n, kRows);
-    int ks = 4, nlin = 4 * row_tiles * la.ngroups;
+    FHead hd;
+    memset(&hd, 0, sizeof(hd));
+    hd.row_tiles = row_tiles;
+    hd.ks = 4;
+    int nlin = 4 * row_tiles * la.ngroups;
     if (nlin + row_tiles > fuse_blocks()) {   // too many 64-column tiles: 256-column ones
-        ks = 1;
+        hd.ks = 1;
         nlin = row_tiles * la.ngroups;
     }
+    int blocks_per_tile[MOPOE_MAX_MODS];
+    for (int z = 0; z < MOPOE_MAX_MODS; ++z) {
+        hd.tiles[z] = hd.ks == 4 ? 4 : kLatentWaves;
+        blocks_per_tile[z] = z < la.ngroups ? (hd.ks == 4 ? 4 : 1) : 0;
+    }
+    // the widest modalities get 32-column blocks while the grid still fits the chip:
+    // a block's MFMA chain is its tiles x K, and the row groups wait for the slowest
+    if (hd.ks == 4)
+        for (;;) {
+            int worst = -1, cost = 0;
+            for (int z = 0; z < la.ngroups; ++z)
+                if (la.g[z].K * hd.tiles[z] > cost) {
+                    cost = la.g[z].K * hd.tiles[z];
+                    worst = z;
+                }
+            if (worst < 0 || hd.tiles[worst] == 2 || la.g[worst].K < 64 ||
+                nlin + 4 * row_tiles + row_tiles > fuse_blocks())
+                break;
+            hd.tiles[worst] = 2;
+            blocks_per_tile[worst] = 8;
+            nlin += 4 * row_tiles;
+        }
+    for (int z = 0; z < MOPOE_MAX_MODS; ++z) {
+        hd.begin[z + 1] = hd.begin[z] + blocks_per_tile[z] * row_tiles;
+        hd.producers += blocks_per_tile[z];
+    }
+    hd.nlin = nlin;
     if (ka.lds.rows == kRows && ka.st.group_rows == 0 && nlin + row_tiles <= fuse_blocks() && !no_fuse()) {
         static thread_local int lds_opted_f = 0;
         const int kp = round_up(maxd < kEncKChunk ? maxd : kEncKChunk, 16);
-        const int lin_lds = (kRows + kRows * (kp + 4) + (ks == 4 ? 4 * kRows * 68 : kRows * 260)) * (int)sizeof(float);
+        const int lin_lds = (kRows + kRows * (kp + 4) + (hd.ks == 4 ? 4 * kRows * 68 : kRows * 260)) * (int)sizeof(float);
         if (lin_lds > lds) lds = lin_lds;
         if (lds > 64 * 1024 && lds > lds_opted_f) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<false>),
@@ -1690,11 +1788,9 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
             lds_opted_f = lds;
         }
         FArgs fa;
+        fa.hd = hd;
         fa.ka = ka;
         fa.la = la;
-        fa.nlin = nlin;
-        fa.row_tiles = row_tiles;
-        fa.ks = ks;
         {
             ProfScope ps(MOPOE_KERNEL_FUSED, s);
             // the lean instantiation for the common training case (see latent_body)

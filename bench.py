@@ -3,30 +3,37 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted
-on): 2-modality joint_elbo MoPoE, input dims 7+444, latent 20, factorized
-style dims [3,20], batch 256 per GPU, float32 (exact-f32 MFMA), synthetic
-N(0,1) data -- a pool of 64 batches resident in HBM before the timed region
--- random-init weights.  One step = encoder/decoder forward, MoPoE fusion,
-joint ELBO, full backward, (gradient all-reduce over RCCL when N > 1), Adam,
-and the step's scalar log written by the kernel into pinned host memory (the
-reference logs every step, run_epochs.py:184).
+Workload of `value` (BASELINE.json configs[1], the configuration the metric is quoted
+on): 2-modality joint_elbo MoPoE, input dims 7+444, latent 20, factorized style dims
+[3,20], batch 256 per GPU, float32 (exact-f32 MFMA), synthetic N(0,1) data -- a pool of
+64 batches resident in HBM before the timed region -- random-init weights.  One step =
+encoder/decoder forward, MoPoE fusion, joint ELBO, full backward, (gradient exchange
+when N > 1), Adam, and the step's scalar log written by the kernel into pinned host
+memory (the reference logs every step, run_epochs.py:184).  W untimed steps, then
+EXACTLY K timed steps between barrier + synchronize pairs, max over ranks.
 
-For N > 1 the driver launches one rank per GPU with torch.distributed.run;
-ranks are data-parallel replicas (weak scaling: 256 samples per GPU per
-step) that exchange the flat gradient buffer once per step: one launch per
-rank over xGMI peer windows (push to every peer, rank-ordered sum, Adam --
-csrc/mopoe_xgmi.inc) after a start-up check of that exchange against the
-gathered inputs on this very node; if the windows cannot be set up or the
-check fails, the step is RCCL all_reduce + the Adam kernel, and `config.exchange`
-says which one ran (MOPOE_EXCHANGE=rccl|xgmi pins it).
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; ranks are
+data-parallel replicas (weak scaling: 256 samples per GPU per step) that exchange the
+flat gradient buffer once per step with RCCL's all-reduce (+ the Adam kernel, which
+also checks that every rank's batch held the same modalities).  MOPOE_EXCHANGE=xgmi
+opts into the peer-window exchange of csrc/mopoe_xgmi.inc (start-up checked against the
+gathered inputs on the node it runs on; it has never run on more than one GPU).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the largest
-share of device time, its duration measured with HIP events on the launch
-stream in a second, instrumented run of the same K steps (events perturb the
-pipeline, so they stay out of the timed region that produces `value`).
-`cpu_baseline` times the CPU oracle (oracle/mopoe_oracle.py, a PyTorch-CPU
-restatement of the reference step) on this box's host cores.
+Prints ONE JSON line (rank 0).  Besides the contract's keys:
+  roofline       the kernel with the largest share of device time, its duration measured
+                 with HIP events on the launch stream in a second, instrumented run of
+                 the same K steps (events perturb the pipeline, so they stay out of the
+                 timed region that produces `value`)
+  cpu_baseline   the CPU oracle (oracle/mopoe_oracle.py, a PyTorch-CPU restatement of the
+                 reference step) on this box's host cores: all cores and 1 thread
+  settled        the same K-step timing after a long warm-up (clocks and caches settled;
+                 `value` itself keeps the W the caller asked for)
+  other_configs  BASELINE.json configs[2] (method poe, batch 1024) and configs[4]
+                 (4 modalities, 15 subsets, batch 512) on one GPU: samples/s + roofline
+  regime_n65536  the kernels at 65,536 rows, where the batch term dominates
+  eager_rocm_baseline   the oracle with its tensors on the GPU (PyTorch-ROCm eager):
+                 the "HIP kernels vs PyTorch-ROCm eager" leg of configs[1]
+(all of these on rank 0 of a 1-GPU run only; --quick leaves the last four out).
 """
 import argparse
 import json
@@ -41,28 +48,46 @@ sys.path.insert(0, ROOT)
 
 import mopoe_amd as mm  # noqa: E402
 
-NAMES = ["clinical", "rois"]
-DIMS = [7, 444]
-STYLE = [3, 20]
-LATENT = 20
-BATCH = 256
-POOL = int(os.environ.get("MOPOE_BENCH_POOL", "64"))   # resident batches (a diagnostic knob; 64 is what is reported)
 HIDDEN = 256
 # MI355X_MICROARCH.md: exact-f32 MFMA peak = vector peak; HBM3E spec
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+POOL = int(os.environ.get("MOPOE_BENCH_POOL", "64"))   # resident batches
+
+CONFIGS = {
+    # BASELINE.json configs[0] / [1] / [3]
+    "C1": dict(names=["clinical", "rois"], dims=[7, 444], style=[3, 20], method="joint_elbo",
+               batch=256, label="configs[1]: 2-modality joint_elbo MoPoE-VAE train step, "
+                                "input_dims 7,444, latent 20, style 3,20, batch 256 per GPU, "
+                                "Adam lr 0.002"),
+    # configs[2]
+    "C3": dict(names=["clinical", "rois"], dims=[7, 444], style=[3, 20], method="poe",
+               batch=1024, label="configs[2]: method poe (joint + unimodal ELBOs), 2 modalities, "
+                                 "batch 1024"),
+    # configs[4] (style dims [3,3,3,3]: experiment.py:133-136 repeats style_dim[0])
+    "C5": dict(names=["clinical", "rois", "snps", "tracts"], dims=[7, 444, 128, 64],
+               style=[3, 3, 3, 3], method="joint_elbo", batch=512,
+               label="configs[4]: 4 modalities (7,444,128,64), joint_elbo over the 15-subset "
+                     "powerset, batch 512 on one GPU"),
+}
+LATENT = 20
+
+
+def make_spec(c):
+    return mm.ModelSpec(c["names"], c["dims"], c["style"], class_dim=LATENT, method=c["method"])
 
 
 def kernel_models(spec, n, fused_adam, world=1):
     """Algorithmic flops / HBM bytes per launch of each kernel at batch n
-    (DESIGN.md section 5 derives these from SURVEY.md section 8d)."""
+    (DESIGN.md section 5 derives these from SURVEY.md section 8d).  Method poe decodes
+    every modality twice (joint latent + its unimodal posterior)."""
     M = spec.num_mods
+    passes = 2 if spec.method == "poe" and spec.poe_unimodal_elbos else 1
     d = sum(spec.input_dim)
     nh = sum(spec.heads_dim(m) for m in range(M))
     dz = sum(spec.input_dim[m] * spec.z_dim(m) for m in range(M))
     zd = sum(spec.z_dim(m) for m in range(M))
-    P = sum(v.numel() for v in spec.param_views(
-        torch.empty(spec.num_floats)).values())
+    P = sum(v.numel() for v in spec.param_views(torch.empty(spec.num_floats)).values())
     D = spec.class_dim
     S = len(spec.subset_keys)
     f = 4
@@ -74,20 +99,19 @@ def kernel_models(spec, n, fused_adam, world=1):
     # heads, decoder, d/dz, d/dh GEMMs; reads h, x, Wh, Wd; writes heads,
     # subsets, joint, z, loc, g_xhat, g_heads, g_pre
     out["k_latent"] = dict(
-        flops=2.0 * n * (2 * HIDDEN * nh + 2 * dz),
+        flops=2.0 * n * (2 * HIDDEN * nh + 2 * passes * dz),
         bytes=f * (n * (2 * HIDDEN * M          # h read (+ mask re-read)
                         + d                      # x
                         + 2 * nh                 # heads, g_heads
                         + 2 * S * D + 2 * D      # subsets, joint
-                        + zd + 2 * d             # z, loc, g_xhat
+                        + passes * (zd + 2 * d)  # z, loc, g_xhat
                         + HIDDEN * M)            # g_pre
                    + 2 * (HIDDEN * nh + dz) + nh + 3 * d))
     # G^T X for W1, Wh, Wd (+ biases) and the Adam read-modify-write
-    wbytes = f * (n * (2 * HIDDEN * M + 2 * d + nh + zd) + P)
+    wbytes = f * (n * (2 * HIDDEN * M + d + nh + passes * (d + zd)) + P)
     if fused_adam:
         wbytes += f * 6 * P
-    out["k_wgrad"] = dict(flops=2.0 * n * (HIDDEN * d + HIDDEN * nh + dz),
-                          bytes=wbytes)
+    out["k_wgrad"] = dict(flops=2.0 * n * (HIDDEN * d + HIDDEN * nh + passes * dz), bytes=wbytes)
     # encoder layer + per-sample chain in one launch (small training batches): h is
     # written (for the weight gradients) and read back by the row groups all the same
     out["k_fused"] = dict(flops=out["k_linear"]["flops"] + out["k_latent"]["flops"],
@@ -101,8 +125,8 @@ def kernel_models(spec, n, fused_adam, world=1):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in
-    separate runs, gfx950 correction applied); None if no summary is there."""
+    (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs,
+    gfx950 correction applied; configs[1]); None if no summary is there."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
@@ -114,52 +138,229 @@ def pmc_traffic(kernel):
         return None
 
 
-def make_pool(device):
-    g = torch.Generator().manual_seed(1234)
-    pool = []
-    for _ in range(POOL):
-        pool.append({n: torch.randn(BATCH, d, generator=g).to(device)
-                     for n, d in zip(NAMES, DIMS)})
-    return pool
+def make_pool(c, device, count=POOL, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    return [{n: torch.randn(c["batch"], d, generator=g).to(device)
+             for n, d in zip(c["names"], c["dims"])} for _ in range(count)]
 
 
-def cpu_baseline(seconds=10.0):
-    """The oracle's train step (forward, loss, autograd backward, Adam) on the
-    host cores: a bounded sample of the same workload, at two thread counts
-    (these ~2,600 tiny ops do not scale with threads; the better one is `value`)."""
+def roofline_of(spec, n, prof, dt_per_step, fused_adam, world, traffic=True):
+    """The roofline object for the kernel with the largest share of device time."""
+    models = kernel_models(spec, n, fused_adam, world)
+    total_ms = sum(ms for _, ms in prof.values()) or 1.0
+    name = max(prof, key=lambda k: prof[k][1])
+    cnt, ms = prof[name]
+    raw_us = {k: v[1] / max(v[0], 1) * 1e3 for k, v in prof.items() if v[0]}
+    # The two event records around a launch add device time of their own (the event-timed
+    # kernels of a step sum to more than the step took in the timed region, where the same
+    # kernels ran back to back).  On one GPU the step IS its kernels, so that excess,
+    # spread evenly over the launches, is the event overhead; it is subtracted.  The
+    # corrected figures agree with the rocprofv3 --kernel-trace averages
+    # (profiles/*_kernel_stats.csv) within 4 %.
+    overhead_us = 0.0
+    if dt_per_step is not None:
+        excess = sum(raw_us.values()) - 1e6 * dt_per_step
+        overhead_us = max(0.0, excess / max(len(raw_us), 1))
+    avg_us = {k: v - overhead_us for k, v in raw_us.items()}
+    avg_s = avg_us[name] * 1e-6
+    km = models[name]
+    t_mfma = km["flops"] / (PEAK_F32_MFMA_TFLOPS * 1e12)
+    t_hbm = km["bytes"] / (PEAK_HBM_GBS * 1e9)
+    if t_mfma >= t_hbm:
+        achieved = km["flops"] / avg_s / 1e12
+        roof = {"bound": "mfma", "achieved": round(achieved, 4), "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5)}
+    else:
+        achieved = km["bytes"] / avg_s / 1e9
+        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS,
+                "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 5)}
+    roof.update({"traffic": pmc_traffic(name) if traffic else None, "kernel": name,
+                 "avg_us": round(avg_s * 1e6, 3),
+                 "share_of_device_time": round(ms / total_ms, 3),
+                 "kernels_avg_us": {k: round(v, 3) for k, v in avg_us.items()},
+                 "kernels_avg_us_with_event_overhead": {k: round(v, 3) for k, v in raw_us.items()},
+                 "event_overhead_us_per_launch": round(overhead_us, 3),
+                 "algorithmic_flops": km["flops"], "algorithmic_bytes": km["bytes"]})
+    return roof
+
+
+def time_single_gpu(c, device, steps, warmup, log=True):
+    """(seconds for `steps` steps, engine, step fn) of config `c` on one GPU."""
+    spec = make_spec(c)
+    eng = mm.MoPoEEngine(spec, device, seed=1234)
+    eng.reset_parameters(torch.Generator().manual_seed(0))
+    pool = make_pool(c, device, count=min(POOL, max(8, (1 << 28) // (4 * c["batch"] * sum(c["dims"])))))
+    ring = [torch.empty(mm._lib.NUM_STATS, dtype=torch.float32).pin_memory() for _ in range(8)]
+
+    def step(i):
+        return eng.train_step(pool[i % len(pool)], apply_adam=True,
+                              stats_host=ring[i % 8] if log else None)[1]
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.check_valid(sync=True)
+    return dt, eng, step, spec
+
+
+def profile_steps(step, first, steps):
+    mm._lib.profile_enable(True)
+    for i in range(steps):
+        step(first + i)
+    torch.cuda.synchronize()
+    prof = mm._lib.profile_read()
+    mm._lib.profile_enable(False)
+    return prof
+
+
+def other_config(key, device, steps=1000, warmup=300):
+    c = CONFIGS[key]
+    dt, eng, step, spec = time_single_gpu(c, device, steps, warmup)
+    prof = profile_steps(step, warmup + steps, steps)
+    loss = float(eng._ws[next(iter(eng._ws))].stats[0])
+    return {"workload": c["label"], "value": round(c["batch"] * steps / dt, 1),
+            "unit": "samples/s", "ms_per_step": round(1e3 * dt / steps, 5), "steps": steps,
+            "warmup": warmup, "dtype": "f32", "final_loss": round(loss, 3),
+            "roofline": roofline_of(spec, c["batch"], prof, dt / steps, True, 1, traffic=False)}
+
+
+def regime_point(device, n=65536):
+    """The kernels of configs[1]'s model at 65,536 rows (the
+    bandwidth / MFMA regime, where the batch term dominates the per-step terms)."""
+    c = dict(CONFIGS["C1"], batch=n)
+    spec = make_spec(c)
+    eng = mm.MoPoEEngine(spec, device, seed=1)
+    eng.reset_parameters(torch.Generator().manual_seed(0))
+    pool = make_pool(c, device, count=2)
+    for i in range(3):
+        eng.train_step(pool[i % 2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 10
+    for i in range(steps):
+        eng.train_step(pool[i % 2])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    mm._lib.profile_enable(True)
+    for i in range(steps):
+        eng.train_step(pool[i % 2])
+    torch.cuda.synchronize()
+    prof = mm._lib.profile_read()
+    mm._lib.profile_enable(False)
+    models = kernel_models(spec, n, True)
+    out = {"rows": n, "ms_per_step": round(1e3 * dt, 4), "samples_per_s": round(n / dt, 1),
+           "kernels": {}}
+    for k, (cnt, ms) in prof.items():
+        if not cnt:
+            continue
+        us = ms / cnt * 1e3
+        km = models[k]
+        out["kernels"][k] = {
+            "avg_us": round(us, 2),
+            "tflops": round(km["flops"] / (us * 1e-6) / 1e12, 2),
+            "frac_f32_mfma_peak": round(km["flops"] / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "algorithmic_gbs": round(km["bytes"] / (us * 1e-6) / 1e9, 1)}
+    return out
+
+
+def oracle_setup(c):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mopoe_oracle as mo
-    cfg = mo.Config(NAMES, DIMS, STYLE, class_dim=LATENT)
+    cfg = mo.Config(c["names"], c["dims"], c["style"], class_dim=LATENT, method=c["method"])
+    return mo, cfg
+
+
+def cpu_baseline(seconds=18.0):
+    """The oracle's train step (forward, loss, autograd backward, Adam) on the host cores:
+    a bounded sample of configs[1]'s workload at 1 thread, at the 16 threads that are a
+    one-GPU job's share of the box, and at ALL host cores (SURVEY.md section 8d asks for
+    all and 1).  These ~2,600 tiny ops per step do not scale with threads -- on a
+    256-thread host the all-cores setting takes seconds per step, so that leg is cut off
+    after two steps; the best setting is `value`."""
+    c = CONFIGS["C1"]
+    mo, cfg = oracle_setup(c)
     g = torch.Generator().manual_seed(1234)
-    pool = [{n: torch.randn(BATCH, d, generator=g) for n, d in zip(NAMES, DIMS)}
+    pool = [{n: torch.randn(c["batch"], d, generator=g) for n, d in zip(c["names"], c["dims"])}
             for _ in range(8)]
-    share = min(16, os.cpu_count() or 1)   # the GPU box's CPU share for one GPU
+    allc = os.cpu_count() or 1
+    try:    # the cores this process may actually run on
+        allc = min(allc, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
     runs = {}
-    for threads in (share, 1):
+    before = torch.get_num_threads()
+    settings = sorted({1, min(16, allc), allc})
+    for threads in settings:
         torch.set_num_threads(threads)
         params = mo.init_params(cfg, 0)
         state = mo.adam_init(params)
         noise = mo.Noise(generator=mo.noise_rng(0))
-        for i in range(5):
+        t0 = time.perf_counter()
+        mo.train_step(params, cfg, pool[0], noise, state)      # warm-up (+ a probe)
+        noise.tape.clear()
+        slow = time.perf_counter() - t0 > 0.5
+        for i in range(0 if slow else 4):
             mo.train_step(params, cfg, pool[i % 8], noise, state)
             noise.tape.clear()
+        budget = seconds / len(settings)
         t0 = time.perf_counter()
         steps = 0
-        while time.perf_counter() - t0 < seconds / 2:
+        while time.perf_counter() - t0 < budget and not (slow and steps >= 2):
             mo.train_step(params, cfg, pool[steps % 8], noise, state)
             noise.tape.clear()
             steps += 1
         dt = time.perf_counter() - t0
-        runs[threads] = (BATCH * steps / dt, steps, dt)
+        runs[threads] = (c["batch"] * steps / dt, steps, dt)
+    torch.set_num_threads(before)
     best = max(runs, key=lambda k: runs[k][0])
     v, steps, dt = runs[best]
     return {"value": round(v, 1), "unit": "samples/s", "cores": best, "kind": "port",
             "sample": "%d steps of the same bs-%d joint_elbo train step (oracle/"
                       "mopoe_oracle.py: PyTorch-CPU float32 restatement of the reference "
-                      "step, autograd backward, Adam) in %.1f s with %d thread(s); "
-                      "host has %d logical CPUs" % (steps, BATCH, dt, best, os.cpu_count() or 0),
+                      "step, autograd backward, Adam) in %.1f s with %d thread(s); host has "
+                      "%d logical CPUs, %d usable by this process" % (
+                          steps, c["batch"], dt, best, os.cpu_count() or 0, allc),
             "ms_per_step": round(1e3 * dt / steps, 3),
-            "other_thread_counts": {str(k): round(v[0], 1) for k, v in runs.items()}}
+            "by_threads": {str(k): {"samples_per_s": round(v[0], 1),
+                                    "ms_per_step": round(1e3 * v[2] / v[1], 3), "steps": v[1]}
+                           for k, v in runs.items()}}
+
+
+def eager_rocm_baseline(device, seconds=6.0):
+    """configs[1]'s "HIP kernels vs PyTorch-ROCm eager": the SAME restatement of the
+    reference step as cpu_baseline, with its tensors on the GPU -- every torch op one or
+    more device launches (a baseline leg only: the oracle is not the product)."""
+    c = CONFIGS["C1"]
+    mo, cfg = oracle_setup(c)
+    g = torch.Generator().manual_seed(1234)
+    pool = [{n: torch.randn(c["batch"], d, generator=g).to(device)
+             for n, d in zip(c["names"], c["dims"])} for _ in range(8)]
+    shapes = [(c["batch"], LATENT)] + [(c["batch"], s) for s in c["style"]]
+    tape = [torch.randn(s, generator=g).to(device) for s in shapes]
+    with torch.device(device):
+        params = type(mo.init_params(cfg, 0))((k, v.to(device)) for k, v in
+                                              mo.init_params(cfg, 0).items())
+        state = mo.adam_init(params)
+        for i in range(5):
+            mo.train_step(params, cfg, pool[i % 8], mo.Noise(tape=tape), state)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps = 0
+        while time.perf_counter() - t0 < seconds:
+            mo.train_step(params, cfg, pool[steps % 8], mo.Noise(tape=tape), state)
+            steps += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"value": round(c["batch"] * steps / dt, 1), "unit": "samples/s",
+            "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+            "what": "oracle/mopoe_oracle.py (PyTorch float32 restatement of the reference "
+                    "step: autograd backward, hand-written torch-semantics Adam) with all "
+                    "tensors on the GPU, PyTorch-ROCm eager, %s" % torch.__version__}
 
 
 def open_xgmi(num_floats, device, rank, world, dist):
@@ -238,9 +439,12 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-log-copy", action="store_true",
-                    help="leave the per-step async D2H of the scalar log out")
+                    help="leave the per-step scalar log into pinned host memory out")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--quick", action="store_true",
+                    help="headline + roofline + cpu_baseline only (no settled / other "
+                         "configs / regime / eager legs)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearse the multi-GPU step (process group, all-reduce, separate "
                          "Adam kernel) even with one rank")
@@ -262,10 +466,12 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    spec = mm.ModelSpec(NAMES, DIMS, STYLE, class_dim=LATENT, method="joint_elbo")
+    c = CONFIGS["C1"]
+    BATCH = c["batch"]
+    spec = make_spec(c)
     eng = mm.MoPoEEngine(spec, device, seed=1234)
     eng.reset_parameters(torch.Generator().manual_seed(0))  # same on all ranks
-    pool = make_pool(device)
+    pool = make_pool(c, device)
     log_ring = [torch.empty(mm._lib.NUM_STATS, dtype=torch.float32).pin_memory()
                 for _ in range(8)]
     fused = dist is None
@@ -273,9 +479,9 @@ def main():
     # ---- the gradient exchange of the N-rank step
     comm, exchange, why, in_backward = None, "none", "", False
     if dist is not None:
-        exchange = os.environ.get("MOPOE_EXCHANGE", "auto")
+        exchange = os.environ.get("MOPOE_EXCHANGE", "rccl")
         if exchange not in ("auto", "xgmi", "rccl"):
-            sys.exit("MOPOE_EXCHANGE must be auto, xgmi or rccl")
+            sys.exit("MOPOE_EXCHANGE must be rccl (default), xgmi or auto")
         if exchange != "rccl":
             comm, why = open_xgmi(spec.num_floats, device, rank, world, dist)
             if comm is None and exchange == "xgmi":
@@ -285,6 +491,9 @@ def main():
             in_backward = check_in_backward(comm, spec, pool[rank % POOL], device, world, dist)
             if not in_backward:
                 why = "exchange inside the weight-gradient launch failed its start-up check"
+        # replicas start identical (parameters, moments, step counts)
+        for t in (eng.params, eng.exp_avg, eng.exp_avg_sq, eng.counters):
+            dist.broadcast(t, 0)
 
     def step(i):
         # the step's scalar log lands in a ring of pinned host buffers, written
@@ -298,7 +507,7 @@ def main():
             comm.allreduce_adam(eng)                # one launch: push, sum, Adam
         elif not fused:
             dist.all_reduce(eng.grads)              # RCCL, one flat buffer
-            eng.adam_step(world=world)
+            eng.adam_step(world=world)              # mean + the ranks' modality check
         return ws
 
     def barrier():
@@ -307,17 +516,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed():
-        for i in range(args.warmup):
-            step(i)
+    def timed(warmup, steps, first=0):
+        for i in range(warmup):
+            step(first + i)
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            ws = step(args.warmup + i)
+        for i in range(steps):
+            ws = step(first + warmup + i)
         barrier()
         return time.perf_counter() - t0, ws
 
-    dt, ws = timed()
+    dt, ws = timed(args.warmup, args.steps)
     if comm is not None:
         # the exchange must have been complete in every step, and the replicas identical
         bad = torch.tensor([comm.timeouts(), 0], device=device, dtype=torch.float64)
@@ -335,16 +544,24 @@ def main():
                   "re-run over RCCL" % (int(bad[0].item()), bool(bad[1].item()))
             comm.close()
             comm, exchange = None, "rccl"
+            eng.recover()
             eng.reset_parameters(torch.Generator().manual_seed(0))
             eng.exp_avg.zero_()
             eng.exp_avg_sq.zero_()
-            dt, ws = timed()
+            dt, ws = timed(args.warmup, args.steps)
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(ws.stats[0].item())
     eng.check_valid(sync=True)     # (raises if any step of the timed region was invalid)
+    if dist is not None:           # replicas must still be identical
+        mine = eng.params.double().sum()
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if lo.item() != hi.item():
+            sys.exit("data-parallel replicas drifted apart")
     if not args.no_log_copy:   # the host ring must have received the same scalar
         host = float(log_ring[(args.warmup + args.steps - 1) % 8][0])
         if host != loss:
@@ -360,9 +577,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: 2-modality joint_elbo MoPoE-VAE "
-                               "train step, input_dims 7,444, latent 20, "
-                               "style 3,20, batch 256 per GPU, Adam lr 0.002",
+        "config": {"workload": c["label"],
                    "global_batch": BATCH * world,
                    "parallelism": "dp%d" % world if dist is not None else "single",
                    "exchange": {"none": "none (single GPU: Adam fused into the "
@@ -373,67 +588,40 @@ def main():
                                          comm is not None and in_backward else
                                          "one launch per rank over xGMI peer windows: push "
                                          "to every peer, rank-ordered sum, Adam"),
-                                "rccl": "RCCL all_reduce of the flat buffer + Adam kernel"
+                                "rccl": "RCCL all_reduce of the flat gradient buffer + Adam "
+                                        "kernel (mean, ranks' modality check)"
                                 }[exchange] + (" [%s]" % why if why else ""),
                    "host_log_every_step": not args.no_log_copy,
                    "final_loss": round(loss, 3)},
     }
 
+    nxt = args.warmup + args.steps
     if rank == 0 and not args.no_roofline:
         # instrumented re-run of the same K steps: HIP events around every
         # launch, on the launch stream
-        mm._lib.profile_enable(True)
-        for i in range(args.steps):
-            step(args.warmup + args.steps + i)
-        torch.cuda.synchronize()
-        prof = mm._lib.profile_read()
-        mm._lib.profile_enable(False)
-        models = kernel_models(spec, BATCH, fused or in_backward, world)
-        total_ms = sum(ms for _, ms in prof.values()) or 1.0
-        name = max(prof, key=lambda k: prof[k][1])
-        cnt, ms = prof[name]
-        raw_us = {k: v[1] / max(v[0], 1) * 1e3 for k, v in prof.items() if v[0]}
-        # The two event records around a launch add device time of their own (the
-        # event-timed kernels of a step sum to more than the step took in the timed
-        # region, where the same kernels ran back to back).  On one GPU the step IS
-        # its kernels, so that excess, spread evenly over the launches, is the event
-        # overhead; it is subtracted.  The corrected figures agree with the
-        # rocprofv3 --kernel-trace averages (profiles/*_kernel_stats.csv) within 4 %.
-        overhead_us = 0.0
-        if dist is None and fused:
-            excess = sum(raw_us.values()) - 1e6 * dt / args.steps
-            overhead_us = max(0.0, excess / max(len(raw_us), 1))
-        avg_us = {k: v - overhead_us for k, v in raw_us.items()}
-        avg_s = avg_us[name] * 1e-6
-        km = models[name]
-        t_mfma = km["flops"] / (PEAK_F32_MFMA_TFLOPS * 1e12)
-        t_hbm = km["bytes"] / (PEAK_HBM_GBS * 1e9)
-        if t_mfma >= t_hbm:
-            achieved = km["flops"] / avg_s / 1e12
-            roof = {"bound": "mfma", "achieved": round(achieved, 4),
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 5)}
-        else:
-            achieved = km["bytes"] / avg_s / 1e9
-            roof = {"bound": "hbm", "achieved": round(achieved, 2),
-                    "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(achieved / PEAK_HBM_GBS, 5)}
-        roof.update({"traffic": pmc_traffic(name), "kernel": name,
-                     "avg_us": round(avg_s * 1e6, 3),
-                     "share_of_device_time": round(ms / total_ms, 3),
-                     "kernels_avg_us": {k: round(v, 3) for k, v in avg_us.items()},
-                     "kernels_avg_us_with_event_overhead":
-                         {k: round(v, 3) for k, v in raw_us.items()},
-                     "event_overhead_us_per_launch": round(overhead_us, 3),
-                     "algorithmic_flops": km["flops"],
-                     "algorithmic_bytes": km["bytes"]})
-        out["roofline"] = roof
+        prof = profile_steps(step, nxt, args.steps)
+        out["roofline"] = roofline_of(spec, BATCH, prof,
+                                      dt / args.steps if (dist is None and fused) else None,
+                                      fused or in_backward, world)
     elif dist is not None and not args.no_roofline:
         for i in range(args.steps):   # keep the collectives matched
-            step(args.warmup + args.steps + i)
+            step(nxt + i)
         torch.cuda.synchronize()
+    nxt += args.steps
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    single = rank == 0 and world == 1 and dist is None
+    if single and not args.quick:
+        # the same K steps once clocks and caches have settled (a short --warmup leaves
+        # the first steps of the timed region on a cold chip; `value` keeps what was asked)
+        sdt, _ = timed(max(1000 - (nxt - 0), 300), args.steps, first=nxt)
+        out["settled"] = {"ms_per_step": round(1e3 * sdt / args.steps, 5),
+                          "value": round(BATCH * args.steps / sdt, 1), "unit": "samples/s",
+                          "after_steps": nxt + max(1000 - nxt, 300)}
+        eng.check_valid(sync=True)
+        out["other_configs"] = {k: other_config(k, device) for k in ("C3", "C5")}
+        out["regime_n65536"] = regime_point(device)
+        out["eager_rocm_baseline"] = eager_rocm_baseline(device)
+    if single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if comm is not None:
         comm.close()

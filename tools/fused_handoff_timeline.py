@@ -20,9 +20,13 @@ for it in range(60):
     c = eng.counters.cpu().view(torch.int32)
     s = ws._stats_all.cpu().view(torch.int32)
     lat = s[128:128 + 32].view(16, 2)
-    rows.append([int(s[128 + 45])] + [int(c[64 + 16 + i]) for i in range(8)] + [int(s[128 + 47]), int(s[128 + 48]), int(lat[1, 0])])
+    rows.append([int(s[128 + 45])] + [int(c[64 + 16 + i]) for i in range(8)] + [int(s[128 + 47]), int(s[128 + 48]), int(lat[1, 0])]
+                + [int(c[64 + 32 + i]) for i in range(7)] + [int(s[128 + 50 + i]) for i in range(5)])
 r = np.array(rows, dtype=np.int64) & 0xFFFFFFFF
 rel = ((r - r[:, :1] + (1 << 31)) % (1 << 32) - (1 << 31)) / 100.0
 med = np.median(rel, axis=0)
 names = ["consumer entry"] + ["producer z%d cg%d stores issued" % (i // 4, i % 4) for i in range(8)] + ["consumer ready to wait", "consumer saw the flag", "S0 end"]
+names += ["  producer z1 cg0: entry", "  x and W loads issued", "  x tile in LDS (barrier)", "  MFMAs done",
+          "  K parts parked (barrier)", "  stores drained", "  flag raised"]
+names += ["  consumer: before the x requests", "  x requested", "  noise drawn", "  pads zeroed", "  x parked"]
 for nm, v in zip(names, med): print("%-34s %7.2f us" % (nm, v))

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Diagnostic: where the fused launch's time goes in a build WITHOUT in-kernel stamps (a
+stamp reads the realtime counter through the scalar memory path and so waits for every
+scalar load in flight: the stamped timeline serialises what normally overlaps).
+Uses the -DMOPOE_KNOCK build (make -C .../csrc knock): MOPOE_KNOCK is a bit mask of
+phases of a row group that are left out; the launch is timed with HIP events, phase by
+phase, and the difference to the full launch is that phase's share of the critical
+path.  Results of such launches are garbage (no update is applied); only time counts.
+    python tools/knockout.py [N]"""
+import os
+import sys
+
+os.environ.setdefault("MOPOE_LIB", "libmopoe_hip_knock.so")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import mopoe_amd as mm  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+spec = mm.ModelSpec(["clinical", "rois"], [7, 444], [3, 20], method="joint_elbo")
+g = torch.Generator().manual_seed(0)
+pool = [{"clinical": torch.randn(n, 7, generator=g).cuda(),
+         "rois": torch.randn(n, 444, generator=g).cuda()} for _ in range(16)]
+PHASES = ["wait for the producers", "noise", "x tiles", "h -> LDS", "S1 heads MFMA",
+          "S2b fusion fwd", "S3 decoder units", "KL sums", "S4 g_z", "S5 fusion bwd",
+          "S6 g_pre", "LDS zeroing", "heads W prefetch", "kernarg prefetch"]
+
+
+def run(mask):
+    os.environ["MOPOE_KNOCK"] = str(mask)
+    eng = mm.MoPoEEngine(spec, "cuda", seed=1)
+    eng.check_valid = lambda sync=False: None
+    for i in range(200):
+        eng.train_step(pool[i % 16])
+    torch.cuda.synchronize()
+    mm._lib.profile_enable(True)
+    for i in range(1500):
+        eng.train_step(pool[i % 16])
+    torch.cuda.synchronize()
+    prof = mm._lib.profile_read()
+    mm._lib.profile_enable(False)
+    return prof["k_fused"][1] / prof["k_fused"][0] * 1e3
+
+
+full = run(0)
+print("k_fused, all phases (HIP events, incl. ~2 us of event overhead): %.2f us" % full)
+for i, name in enumerate(PHASES):
+    t = run(1 << i)
+    print("  without %-24s %6.2f us   (%+.2f)" % (name, t, t - full))
+allk = run((1 << len(PHASES)) - 1)
+print("  without all of them             %6.2f us   (%+.2f)" % (allk, allk - full))
+fwd = run(sum(1 << i for i in (4, 5, 6, 7, 8, 9, 10)))
+print("  without S1..S6                  %6.2f us   (%+.2f)" % (fwd, fwd - full))
+ALL = (1 << len(PHASES)) - 1
+for label, mask in (("no producers (row groups in full)", 1 << 14 | 1),
+                    ("no producers, row groups without all phases", 1 << 14 | ALL),
+                    ("no row groups (producers in full)", 1 << 15),
+                    ("neither (the bare launch of 224 workgroups)", 1 << 14 | 1 << 15)):
+    t = run(mask)
+    print("  %-46s %6.2f us   (%+.2f)" % (label, t, t - full))
+again = run(0)
+print("k_fused, all phases again: %.2f us" % again)

@@ -7,7 +7,7 @@
 # pmc_traffic.json}.  Usage: bash tools/profile_round.sh <tag> [bench args]
 set -e -o pipefail
 tag=${1:-r00}; shift || true
-args=${@:---steps 300 --warmup 50 --no-cpu-baseline --no-roofline}
+args=${@:---steps 300 --warmup 50 --no-cpu-baseline --no-roofline --quick}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
