@@ -752,7 +752,7 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
     GSTAMP(a.counters, kCtrStamp + 38, pstamp);
 }
 
-template <bool LEAN>
+template <int FORM>
 __global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value) {
     (void)f_by_value;  // read in place (see k_latent)
     const FArgs& f = *(const FArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value
 #endif
     const int grp = b - hd.nlin;
     int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)grp * f.ka.lds.part_stride + kHandoffWord);
-    latent_body<true, LEAN>(f.ka, lds, grp, flag, hd.producers, &f.la);
+    latent_body<true, FORM>(f.ka, lds, grp, flag, hd.producers, &f.la);
 }
 
 // Scalars of the step from the row tiles' partial sums, in a fixed order
@@ -1699,6 +1699,25 @@ static int fuse_blocks() {
     return v ? atoi(v) : 256;
 }
 
+// Which instantiation of the fused launch serves this step (latent_body's FORM); 0 = the
+// generic one.  MOPOE_NO_LEAN=1 forces the generic form (the forms are bit-identical:
+// tests/test_hip_fused.py).
+int launch_form(const KArgs& ka) {
+    const mopoe_model& mdl = ka.mdl;
+    const mopoe_step& st = ka.st;
+    const LatentLds& L = ka.lds;
+    if (getenv("MOPOE_NO_LEAN") != nullptr) return 0;
+    if (!st.backward || !st.sample || st.joint_mode != MOPOE_JOINT_MIXTURE || st.group_rows != 0 ||
+        L.rows != kRows)
+        return 0;
+    for (int k = 0; k < st.num_subsets; ++k)
+        if (st.sub_kind[k] == MOPOE_SUB_SLICES) return 0;
+    if (mdl.num_mods <= 2 && L.single_pass && L.s3_nt == 2 && L.xs_early && st.num_jobs <= 2) return 1;
+    if (mdl.num_mods <= 2 && !L.single_pass && L.s3_nt == 2 && L.xs_early && st.num_jobs <= 4) return 2;
+    if (mdl.num_mods <= 4 && L.single_pass && L.s3_nt == 4 && !L.xs_early && st.num_jobs <= 4) return 3;
+    return 0;
+}
+
 int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) {
     const mopoe_model& mdl = ka.mdl;
     LinArgs la;
@@ -1779,12 +1798,12 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         const int lin_lds = (kRows + kRows * (kp + 4) + (hd.ks == 4 ? 4 * kRows * 68 : kRows * 260)) * (int)sizeof(float);
         if (lin_lds > lds) lds = lin_lds;
         if (lds > 64 * 1024 && lds > lds_opted_f) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) return fail(MOPOE_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            const void* forms[] = {reinterpret_cast<const void*>(k_fused<0>), reinterpret_cast<const void*>(k_fused<1>),
+                                   reinterpret_cast<const void*>(k_fused<2>), reinterpret_cast<const void*>(k_fused<3>)};
+            for (const void* fn : forms) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) return fail(MOPOE_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            }
             lds_opted_f = lds;
         }
         FArgs fa;
@@ -1793,16 +1812,13 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         fa.la = la;
         {
             ProfScope ps(MOPOE_KERNEL_FUSED, s);
-            // the lean instantiation for the common training case (see latent_body)
-            bool lean = mdl.num_mods <= 2 && ka.st.backward && ka.st.sample && ka.lds.single_pass && ka.lds.s3_nt == 2 &&
-                        ka.lds.xs_early && ka.st.joint_mode == MOPOE_JOINT_MIXTURE &&
-                        getenv("MOPOE_NO_LEAN") == nullptr;
-            for (int k = 0; k < ka.st.num_subsets; ++k)
-                lean = lean && ka.st.sub_kind[k] != MOPOE_SUB_SLICES;
-            if (lean)
-                hipLaunchKernelGGL(k_fused<true>, dim3(nlin + row_tiles), dim3(kLatentThreads), (size_t)lds, s, fa);
-            else
-                hipLaunchKernelGGL(k_fused<false>, dim3(nlin + row_tiles), dim3(kLatentThreads), (size_t)lds, s, fa);
+            const dim3 grid(nlin + row_tiles), block(kLatentThreads);
+            switch (launch_form(ka)) {   // (the instantiations are described in latent_body)
+                case 1: hipLaunchKernelGGL(k_fused<1>, grid, block, (size_t)lds, s, fa); break;
+                case 2: hipLaunchKernelGGL(k_fused<2>, grid, block, (size_t)lds, s, fa); break;
+                case 3: hipLaunchKernelGGL(k_fused<3>, grid, block, (size_t)lds, s, fa); break;
+                default: hipLaunchKernelGGL(k_fused<0>, grid, block, (size_t)lds, s, fa); break;
+            }
         }
         return check_launch("k_fused");
     }

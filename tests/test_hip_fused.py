@@ -36,3 +36,48 @@ def test_fused_launch_is_bit_identical_to_three_launches(n, monkeypatch):
     for a, b, c in zip(fused, again, plain):
         assert torch.equal(a, b)
         assert torch.equal(a, c)
+
+
+SHAPES = {
+    # BASELINE configs[2]: method poe -> the two-pass form of the fused launch
+    "C3_poe_bs1024": dict(names=["clinical", "rois"], dims=[7, 444], style=[3, 20], method="poe",
+                          n=1024, steps=300),
+    # configs[4]: four modalities, 15 subsets -> the four-modality form
+    "C5_four_mods_bs512": dict(names=["a", "b", "c", "d"], dims=[7, 444, 128, 64],
+                               style=[3, 3, 3, 3], method="joint_elbo", n=512, steps=300),
+    "poe_nofact_bs256": dict(names=["clinical", "rois"], dims=[7, 444], style=[3, 20],
+                             method="poe", n=256, steps=300, factorized=False),
+}
+
+
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+def test_specialised_forms_are_bit_identical_to_the_generic_one(shape, monkeypatch):
+    """The instantiations of the fused launch (latent_body's FORM: constant trip counts,
+    narrower expert arrays, compiled-out paths) must change nothing but the time:
+    MOPOE_NO_LEAN=1 runs the generic form, MOPOE_NO_FUSE=1 the three launches."""
+    c = SHAPES[shape]
+
+    def train():
+        spec = mm.ModelSpec(c["names"], c["dims"], c["style"], method=c["method"],
+                            factorized=c.get("factorized", True))
+        eng = mm.MoPoEEngine(spec, "cuda", seed=9)
+        eng.reset_parameters(torch.Generator().manual_seed(0))
+        g = torch.Generator().manual_seed(2)
+        pool = [{k: torch.randn(c["n"], d, generator=g).cuda()
+                 for k, d in zip(c["names"], c["dims"])} for _ in range(4)]
+        for i in range(c["steps"]):
+            eng.train_step(pool[i % 4])
+        eng.check_valid(sync=True)
+        return eng.params.clone(), eng.exp_avg_sq.clone()
+
+    for v in ("MOPOE_NO_LEAN", "MOPOE_NO_FUSE"):
+        monkeypatch.delenv(v, raising=False)
+    special = train()
+    monkeypatch.setenv("MOPOE_NO_LEAN", "1")
+    generic = train()
+    monkeypatch.delenv("MOPOE_NO_LEAN")
+    monkeypatch.setenv("MOPOE_NO_FUSE", "1")
+    plain = train()
+    for a, b, d in zip(special, generic, plain):
+        assert torch.equal(a, b)
+        assert torch.equal(a, d)
