@@ -612,7 +612,10 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
     constexpr int CH = 8, kStage = 2, kCols = 16 * kTiles;
     static_assert(KS * kTiles <= kLatentWaves, "a wave per (tile, K part)");
     const int N = a.n, K = g.K;
-    const bool vec = K % 4 == 0 || g.wslack;   // W: 4-wide reads stay inside the buffer
+    // (W is a segment of the flat parameter buffer, its bias follows it: 4-wide reads of a
+    //  row whose length is not a multiple of 4 stay inside the buffer -- g.wslack is set by
+    //  the only caller; the per-element form of linear_tile and its sixteen precomputed
+    //  offsets per fragment batch, which the register allocator spilled, are not needed here)
     const int n0 = rt * kRows;
     const bool busy = wave < KS * kTiles;      // (wave-uniform)
     const int tile = busy ? wave / KS : 0, part = wave % KS;
@@ -638,15 +641,9 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
         const rsrc_t wr = make_rsrc(g.W + kc0, ((size_t)g.ncols * K + (g.wslack ? 3 : 0)) * sizeof(float));
         auto load_w = [&](int i0, f32x4 (&b)[CH]) __attribute__((always_inline)) {
             if (!busy) return;
-            if (vec) {
 #pragma unroll
-                for (int c = 0; c < CH; ++c)  // k >= Kc is out of range -> 0
-                    b[c] = glb_b4_nt<true>(wr, K, Kc, j0, 16 * (part + KS * (i0 + c)), lane);
-            } else {
-#pragma unroll
-                for (int c = 0; c < CH; ++c)
-                    b[c] = glb_b4_nt<false>(wr, K, Kc, j0, 16 * (part + KS * (i0 + c)), lane);
-            }
+            for (int c = 0; c < CH; ++c)  // k >= Kc is out of range -> 0
+                b[c] = glb_b4_nt<true>(wr, K, Kc, j0, 16 * (part + KS * (i0 + c)), lane);
         };
         f32x4 b[CH];
         if (kc0 > 0) __syncthreads();
@@ -782,6 +779,9 @@ __global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value
         if (hd.ks == 4) {
             const int two = hd.tiles[z] == 2;
             const int ncg = two ? 8 : 4;
+            // (An XCD-aware map of the (row tile, column group) grid -- 4 x 2 over the classes
+            //  b % 8 -- takes 0.45 MB of counted fetch off the launch and costs 0.15 us, the
+            //  next kernel then finding its operands in other XCDs' L2s: measured, not kept.)
             const int cg = local % ncg, rt = local / ncg;
             int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * stride + kHandoffWord);
             if (two)
