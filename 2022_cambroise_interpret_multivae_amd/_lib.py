@@ -13,7 +13,7 @@ MAX_SUBSETS = 31
 MAX_JOBS = 10
 HIDDEN = 256
 ROWS = 16
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_RANKS = 8
 IPC_HANDLE_BYTES = 64
 
@@ -117,6 +117,7 @@ class Buffers(C.Structure):
         ("g_xhat", _ptr * MAX_MODS),
         ("g_heads", _ptr * MAX_MODS),
         ("g_pre", _ptr * MAX_MODS),
+        ("wfrag", _ptr),
         ("partials", _ptr),
     ]
 
@@ -138,6 +139,8 @@ SYMBOLS = {
     "mopoe_model_layout": (C.c_int, [C.POINTER(Model)]),
     "mopoe_ldz": (C.c_int, [C.POINTER(Model), C.c_int]),
     "mopoe_partials_stride": (C.c_int, [C.POINTER(Model)]),
+    "mopoe_wfrag_floats": (C.c_int, [C.POINTER(Model)]),
+    "mopoe_wfrag_refresh": (C.c_int, [C.POINTER(Model), C.POINTER(Buffers), C.c_void_p]),
     "mopoe_row_groups": (C.c_int, [C.POINTER(Model), C.POINTER(Step)]),
     "mopoe_latent_lds_bytes": (C.c_int, [C.POINTER(Model), C.POINTER(Step)]),
     "mopoe_forward": (C.c_int, [C.POINTER(Model), C.POINTER(Step),
@@ -187,7 +190,7 @@ def _load():
                C.sizeof(Adam), Step.job_eps_content.offset,
                Step.comp_w.offset, Buffers.partials.offset,
                Model.num_floats.offset, Buffers.status_host.offset,
-               Model.off_ctrl.offset]
+               Model.off_ctrl.offset, Buffers.wfrag.offset]
     for which, mine in enumerate(mirrors):
         if lib.mopoe_sizeof(which) != mine:
             raise ImportError("ctypes mirror %d disagrees with the C struct "

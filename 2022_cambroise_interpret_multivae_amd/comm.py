@@ -62,13 +62,7 @@ class XgmiComm:
         exp_avg / exp_avg_sq: `all_reduce(grads); adam_step(1/world)` in one launch."""
         if present_mask is None:
             present_mask = engine.last_present_mask
-        b = L.Buffers()
-        b.params = L.ptr(engine.params)
-        b.grads = L.ptr(engine.grads)
-        b.exp_avg = L.ptr(engine.exp_avg)
-        b.exp_avg_sq = L.ptr(engine.exp_avg_sq)
-        b.counters = L.ptr(engine.counters)
-        b.status_host = L.ptr(engine.status_host)
+        b = engine._optim_buffers(L.Buffers())
         L.check(L.lib.mopoe_comm_allreduce_adam(
             self._c, engine.spec.c_model, present_mask, b, C.byref(engine.adam),
             L.stream_ptr()), "mopoe_comm_allreduce_adam")

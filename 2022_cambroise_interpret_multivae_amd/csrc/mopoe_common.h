@@ -52,6 +52,36 @@ HD int lvo_part_off(const mopoe_model& m, int i) {
 HD int lvo_slot_stride(const mopoe_model& m, int i) { return round_up(m.input_dim[i], 4); }
 HD int partials_stride(const mopoe_model& m) { return lvo_part_off(m, m.num_mods); }
 
+// Fragment-major weight copies of the four-row form (latent_body FORM 4).  The 4x4x1 MFMA
+// wants, per K step, column l of a 64-column tile in lane l; with nn.Linear's (out, in)
+// layout that is 64 different rows per wave-load.  WF[tile][k/4][lane][4] = W[64 tile +
+// lane][k .. k+3] makes it one contiguous kilobyte for four K steps.  Per modality: the
+// heads weights (K = 256) and the decoder weights (K = z_dim, padded to 4).
+struct WFrag {
+    int whf[MOPOE_MAX_MODS], wdf[MOPOE_MAX_MODS];   // float offsets into mopoe_buffers.wfrag
+    int t1[MOPOE_MAX_MODS], t3[MOPOE_MAX_MODS];     // 64-column tiles: heads, decoder
+    int k4d[MOPOE_MAX_MODS];                        // K/4 of the decoder (heads: 64)
+    int total;
+};
+// float offset of the piece W[r][4 k4 .. 4 k4 + 3] inside a copy with K/4 = k4n
+HD int wfrag_piece(int r, int k4, int k4n) { return (((r >> 6) * k4n + k4) * 64 + (r & 63)) * 4; }
+HD WFrag wfrag_layout(const mopoe_model& m) {
+    WFrag w;
+    int off = 0;
+    for (int i = 0; i < MOPOE_MAX_MODS; ++i) {
+        const bool on = i < m.num_mods;
+        w.t1[i] = on ? cdiv(heads_dim(m, i), 64) : 0;
+        w.t3[i] = on ? cdiv(m.input_dim[i], 64) : 0;
+        w.k4d[i] = on ? cdiv(z_dim(m, i), 4) : 0;
+        w.whf[i] = off;
+        off += w.t1[i] * (kHid / 4) * 256;
+        w.wdf[i] = off;
+        off += w.t3[i] * w.k4d[i] * 256;
+    }
+    w.total = off;
+    return w;
+}
+
 // ---------------------------------------------------------------------------
 // LDS carve-up of the fused latent kernel (floats), computed on the host and
 // handed over in the kernel arguments.  Region R0 is time-shared: the hidden
@@ -159,6 +189,23 @@ struct LatentLds {
     // thing, one 16-byte store per thread (prefix table in float4 units)
     int zr_begin[MOPOE_MAX_JOBS + MOPOE_MAX_MODS + 1];
     int zr_off[MOPOE_MAX_JOBS + MOPOE_MAX_MODS];
+    // four-row groups (latent_body FORM 4): K parts of the GEMM stages, one per wave
+    int q1_begin[MOPOE_MAX_MODS + 1], q1_kper, q1_parts;   // heads: per present modality (tile, K part) units
+    int q3_begin[MOPOE_MAX_JOBS + 1];            // decoder: 64-column tiles per job
+    int q4_begin[MOPOE_MAX_JOBS + 1], q4_kper;   // dL/dz: K parts (of d_m) per job
+    int q6_begin[MOPOE_MAX_MODS + 1], q6_kper;   // dL/dh: K parts (of nh_m) per present modality
+    int qred;                                    // LDS: partial tiles [16 waves][4 rows][256]
+    struct alignas(16) Q4Unit {                  // dL/dz: all a wave needs, in one scalar load
+        int nk4;                                 // K steps of four that hold rows < round_up(d_m, 16); -1: no unit
+        int ga;                                  // LDS: g_xhat tile + this part's first column
+        int wl;                                  // LDS: Wd copy + this part's first row
+        int ldx_zd;                              // ld of the tile << 8 | row length of the copy
+    } q4u[16];
+    int wdl[MOPOE_MAX_MODS];                     // LDS: copy of Wd_m (behind the 64-column partials)
+    int wd_units[2];                             // 1 KB units (64 pieces of 16 bytes) of it, per present modality
+    int wd_valid[2];                             // pieces that hold weights (the rest: zero rows)
+    int quad_ok;
+    WFrag wf;                                    // fragment-major weight copies (mopoe_buffers.wfrag)
     int rows;                          // batch rows a group owns (16, 8, 4, 2 or 1)
     int rd;                            // round_up(rows * class_dim, 4): stride of a KL-term slab
     int fits;                          // the carve-up fits the 160 KiB budget
@@ -491,6 +538,14 @@ HD int latent_groups(const mopoe_model& m, const mopoe_step& st, int waves) {
 // ---------------------------------------------------------------------------
 #if defined(__HIPCC__)
 
+// v_mfma_f32_4x4x1_16B_f32: sixteen independent 4x4 blocks, K = 1, the same FLOP rate as
+// the 16x16x4 form (8 cycles for 512 flops).  D[vgpr i][lane l] += A[lane 4*(l/4)+i] *
+// B[lane l] (tools/mfma4_probe.hip): with A = X[row l%4][k] in every block and B =
+// W[k][column l], lane l ends up with column l of FOUR batch rows.
+DEV f32x4 mfma_4x4x1(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
 DEV f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     // v_mfma_f32_16x16x4_f32: exact f32 fmaf chain (guide section 3).
     // A: lane l holds A[row l&15][k l>>4]; B: B[k l>>4][col l&15];
@@ -501,6 +556,19 @@ DEV f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
 // A packed descriptor record out of the argument block, fetched whole: 8-dword vector
 // loads, which become s_load_dwordx8 (left to itself the compiler loads the fields one
 // dword at a time, next to their uses, and waits for each).
+// (a 16-byte record: one s_load_dwordx4)
+template <class T>
+DEV T load_rec16(const T& src) {
+    static_assert(sizeof(T) == 16 && alignof(T) >= 16, "a 16-byte record");
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    union U {
+        T t;
+        v4i v;
+        DEV U() {}
+    } u;
+    u.v = *reinterpret_cast<const v4i*>(&src);
+    return u.t;
+}
 template <class T>
 DEV T load_rec(const T& src) {
     static_assert(sizeof(T) % 32 == 0 && alignof(T) >= 32, "records are 32-byte multiples");

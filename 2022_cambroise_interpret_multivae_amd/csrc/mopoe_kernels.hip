@@ -136,6 +136,8 @@ struct LinArgs {
     int32_t num_mods;      // modalities of the model (the Adam records of step_begin)
     int32_t spins;         // fused launch: polls of a row group before it gives up
     int32_t knock;         // (diagnostic build -DMOPOE_KNOCK: phases to leave out)
+    int32_t sig_n, sig_stride, sig_groups;   // fused launch: row groups per 16-row tile, words
+                                             // between their flags, row groups in all
     mopoe_adam adam;
     LinGroup g[MOPOE_MAX_MODS];
 };
@@ -589,8 +591,9 @@ struct alignas(64) FHead {
     int32_t ks;          // 4: K over four waves per column tile; 1: a wave per column tile
     int32_t producers;   // encoder-layer blocks per row tile (what a row group waits for)
     int32_t begin[MOPOE_MAX_MODS + 1];  // first block of encoder group z
-    int32_t tiles[MOPOE_MAX_MODS];      // 16-column tiles per block of group z (ks == 4: 4 or 2)
-    int32_t pad;
+    int32_t tiles[MOPOE_MAX_MODS];      // 16-column tiles per block of group z (ks == 4: 4, 2,
+                                        // or 16 = one 256-column block, K <= 16 unsplit)
+    int32_t gpt;         // row groups per 16-row tile: 1, or 4 (four-row groups)
 };
 static_assert(sizeof(FHead) == 64, "one scalar cache line");
 struct FArgs {
@@ -745,8 +748,41 @@ DEV void linear_block16(const LinArgs& a, const LinGroup& g, float* lds, int rt,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GSTAMP(a.counters, kCtrStamp + 37, pstamp);
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // one add per row group that reads these rows (four-row groups: up to four of them,
+    // their flags a slab apart)
+    if (tid < a.sig_n && rt * a.sig_n + tid < a.sig_groups)
+        __hip_atomic_fetch_add(flag + (size_t)tid * a.sig_stride, 1, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
     GSTAMP(a.counters, kCtrStamp + 38, pstamp);
+}
+
+// Rebuilds the fragment-major copies of the head and decoder weights (WFrag) from the
+// parameters: a 16-byte piece W[r][4 k4 ..] moves to WF[r / 64][k4][r % 64].  The copies
+// follow the parameters by themselves wherever THIS library rewrites them (the Adam
+// epilogue of k_wgrad stores both; mopoe_adam_step and the exchanging update run this
+// kernel behind theirs); after any other writer -- an initialisation, a checkpoint, a
+// broadcast -- mopoe_wfrag_refresh runs it.
+__global__ __launch_bounds__(256) void k_wfrag(const mopoe_model mdl, const float* __restrict__ params,
+                                               float* __restrict__ wfrag) {
+    const WFrag wf = wfrag_layout(mdl);
+    const rsrc_t pr = make_rsrc(params, (size_t)mdl.num_floats * sizeof(float));
+    const rsrc_t wr = make_rsrc(wfrag, (size_t)wf.total * sizeof(float));
+    const int t0 = blockIdx.x * 256 + threadIdx.x, nthr = gridDim.x * 256;
+    for (int m = 0; m < mdl.num_mods; ++m) {
+        const int nh = heads_dim(mdl, m), zd = z_dim(mdl, m), dm = mdl.input_dim[m], k4d = wf.k4d[m];
+        for (int p = t0; p < nh * (kHid / 4); p += nthr) {
+            const int r = p >> 6, k4 = p & 63;
+            const f32x4 v = ldg4(pr, (uint32_t)(mdl.off_wh[m] + r * kHid + 4 * k4) * 4u);
+            stg4_wt(wr, (uint32_t)(wf.whf[m] + wfrag_piece(r, k4, kHid / 4)) * 4u, v);
+        }
+        for (int p = t0; p < dm * k4d; p += nthr) {
+            const int r = p / k4d, k4 = p - r * k4d;
+            f32x4 v = ldg4(pr, (uint32_t)(mdl.off_wd[m] + r * zd + 4 * k4) * 4u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 4 * k4 + e < zd ? v[e] : 0.f;   // (the next row's start)
+            stg4_wt(wr, (uint32_t)(wf.wdf[m] + wfrag_piece(r, k4, k4d)) * 4u, v);
+        }
+    }
 }
 
 template <int FORM>
@@ -776,21 +812,26 @@ __global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value
         const int z = find_seg<MOPOE_MAX_MODS>(hd.begin, b);
         const int local = b - hd.begin[z];
         const int stride = f.ka.lds.part_stride;
-        if (hd.ks == 4) {
+        const int ks = hd.ks & 0xFF;
+        if (ks == 4 && hd.tiles[z] == kLatentWaves) {   // K <= 16: one 256-column block
+            const int rt = local;
+            int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * hd.gpt * stride + kHandoffWord);
+            linear_block16<1>(a, a.g[z], lds, rt, 0, tid, lane, wave, flag, z);
+        } else if (ks == 4) {
             const int two = hd.tiles[z] == 2;
             const int ncg = two ? 8 : 4;
             // (An XCD-aware map of the (row tile, column group) grid -- 4 x 2 over the classes
             //  b % 8 -- takes 0.45 MB of counted fetch off the launch and costs 0.15 us, the
             //  next kernel then finding its operands in other XCDs' L2s: measured, not kept.)
             const int cg = local % ncg, rt = local / ncg;
-            int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * stride + kHandoffWord);
+            int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * hd.gpt * stride + kHandoffWord);
             if (two)
                 linear_block16<4, 2>(a, a.g[z], lds, rt, cg, tid, lane, wave, flag, z);
             else
                 linear_block16<4, 4>(a, a.g[z], lds, rt, cg, tid, lane, wave, flag, z);
         } else {
             const int rt = local;
-            int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * stride + kHandoffWord);
+            int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * hd.gpt * stride + kHandoffWord);
             linear_block16<1>(a, a.g[z], lds, rt, 0, tid, lane, wave, flag, z);
         }
         asm volatile("" ::"s"(karg_sink));
@@ -809,6 +850,26 @@ __global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value
 // (run_epochs.py:89-128, mm_div.py:92-111, kl_div.py:7-14; utils/TBLogger.py:26-37 for
 // the latent means).  One block; one thread per scalar -- a single thread walking the
 // descriptor arrays pays one scalar-memory round trip per element and took ~11 us.
+// sum of q[t * stride], t0 <= t < t1, in a fixed order: sixteen interleaved accumulators,
+// sixteen loads in flight (a serial walk pays a trip to the L2 per element)
+DEV float strided_sum(const float* __restrict__ q, int t0, int t1, size_t stride) {
+    float s[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s[k] = 0.f;
+    for (int t = t0; t < t1; t += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = q[(size_t)min(t + k, t1 - 1) * stride];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s[k] += t + k < t1 ? v[k] : 0.f;
+    }
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+        for (int k = 0; k < w; ++k) s[k] += s[k + w];
+    return s[0];
+}
+
 template <int THREADS>  // block size
 DEV void finalize_stats(const KArgs& a, int tid) {
     constexpr int SLICES = THREADS / kStatStride;
@@ -823,24 +884,12 @@ DEV void finalize_stats(const KArgs& a, int tid) {
     const int stride = a.lds.part_stride;
     if (tid < SLICES * kStatStride) {
         // partial index p = tid % kStatStride, tile slice = tid / kStatStride; slices
-        // summed in order.  Four interleaved accumulators keep four loads in flight per
-        // thread (a 50,000-row forward has 3125 row groups to add up).
+        // summed in order, sixteen loads in flight per thread (a 50,000-row forward has
+        // 3125 row groups to add up).
         const int p = tid % kStatStride, sl = tid / kStatStride;
         const int per = cdiv(tiles, SLICES);
         const int t1 = min((sl + 1) * per, tiles);
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        if (p < kNumPart) {
-            const float* q = buf.partials + p;
-            int t = sl * per;
-            for (; t + 3 < t1; t += 4) {
-                s0 += q[(size_t)t * stride];
-                s1 += q[(size_t)(t + 1) * stride];
-                s2 += q[(size_t)(t + 2) * stride];
-                s3 += q[(size_t)(t + 3) * stride];
-            }
-            for (; t < t1; ++t) s0 += q[(size_t)t * stride];
-        }
-        slab[sl][p] = (s0 + s1) + (s2 + s3);
+        slab[sl][p] = p < kNumPart ? strided_sum(buf.partials + p, sl * per, t1, (size_t)stride) : 0.f;
     }
     __syncthreads();
     const float fn = (float)st.n;
@@ -922,6 +971,7 @@ struct WJob {
     int32_t tiles_j, tile_begin;
     int32_t mod;           // modality of the parameters (its own Adam step count)
     int32_t xtotal;        // rows of X (the descriptor covers exactly xtotal * ldx floats)
+    int32_t wf_off, wf_k4; // fragment-major copy of this weight (WFrag): float offset or -1, K/4
 };
 
 struct WArgs {
@@ -1193,6 +1243,13 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
                     nv[e] = vo;
                 }
             }
+            if (apply && job.wf_off >= 0) {   // the fragment-major copy follows the weight
+                f32x4 wv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wv[e] = e < nvalid ? np[e] : 0.f;
+                stg4_wt(make_rsrc(buf.wfrag, (size_t)a.lds.wf.total * sizeof(float)),
+                        (uint32_t)(job.wf_off + wfrag_piece(ei, ej >> 2, job.wf_k4)) * 4u, wv);
+            }
             if (nvalid >= 4) {
                 const rsrc_t rg = make_rsrc(buf.grads, pbytes);
                 stg4_wt(rg, (uint32_t)widx * 4u, g);
@@ -1227,7 +1284,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         const int tiles = cdiv(a.st.n, a.lds.rows);
         const int stride = a.lds.part_stride;
         // d loss / d decoders.<m>.logvar: sum of the row groups' partials.  A block
-        // owns 64 columns; its waves take an equal share of the groups each (four
+        // owns 64 columns; its waves take an equal share of the groups each (sixteen
         // loads in flight per thread) and are added in fixed order through LDS.
         int m = 0;
         while (lb >= w.lvo_block_begin[m + 1]) ++m;
@@ -1245,16 +1302,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
             for (int sl = 0; sl < slots; ++sl) {
                 const float* p = buf.partials + a.lds.lvo_off[m] +
                                  sl * lvo_slot_stride(a.mdl, m) + col;
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                int t = t0;
-                for (; t + 3 < t1; t += 4) {
-                    s0 += p[(size_t)t * stride];
-                    s1 += p[(size_t)(t + 1) * stride];
-                    s2 += p[(size_t)(t + 2) * stride];
-                    s3 += p[(size_t)(t + 3) * stride];
-                }
-                for (; t < t1; ++t) s0 += p[(size_t)t * stride];
-                g += (s0 + s1) + (s2 + s3);
+                g += strided_sum(p, t0, t1, (size_t)stride);
             }
         }
         blk[0][wave * 64 + lane] = g;
@@ -1653,9 +1701,137 @@ void bind_buffers(KArgs& ka, const mopoe_buffers& buf) {
         if (!ka.buf.x_rows[m]) ka.buf.x_rows[m] = ka.st.n;
 }
 
+// Four-row groups ("quad" form of the fused launch, latent_body FORM 4): a training step of
+// <= 2 modalities with one decoder pass and at most 256 rows is cut into groups of FOUR
+// rows -- four times the row groups on four times the CUs, each issuing a quarter of the
+// MFMAs.  MOPOE_QUAD=0 turns it off.
+bool quad_step(const mopoe_model& mdl, const mopoe_step& st) {
+    const char* v = getenv("MOPOE_QUAD");
+    if (v && atoi(v) == 0) return false;
+    if (!st.backward || !st.sample || st.joint_mode != MOPOE_JOINT_MIXTURE || st.group_rows != 0 ||
+        st.rows_per_group != 0 || mdl.num_mods > 2 || st.num_jobs > 2 || st.n > 256 || st.n < 4)
+        return false;
+    for (int k = 0; k < st.num_subsets; ++k)
+        if (st.sub_kind[k] == MOPOE_SUB_SLICES) return false;
+    for (int j = 1; j < st.num_jobs; ++j)
+        if (st.job_stream[j] != st.job_stream[0]) return false;
+    return getenv("MOPOE_NO_FUSE") == nullptr && getenv("MOPOE_NO_LEAN") == nullptr;
+}
+// THE layout of a step: every caller (launches, mopoe_row_groups, mopoe_latent_lds_bytes)
+// goes through here, so they agree on the rows per group
+// the work split of the four-row form's GEMM stages (one unit per wave); false: no fit
+bool quad_tables(const mopoe_model& mdl, const mopoe_step& st, LatentLds& L) {
+    // dL/dh: K = nh_m in parts of 8 (two 16-byte reads of the g_heads tile per wave)
+    L.q6_kper = 8;
+    int u = 0, pm = 0;
+    for (int i = 0; i <= MOPOE_MAX_MODS; ++i) L.q6_begin[i] = L.q1_begin[i] = 0;
+    for (int i = 0; i < mdl.num_mods; ++i)
+        if ((st.present_mask >> i) & 1) {
+            L.q6_begin[pm++] = u;
+            u += cdiv(heads_dim(mdl, i), L.q6_kper);
+        }
+    for (int i = pm; i <= MOPOE_MAX_MODS; ++i) L.q6_begin[i] = u;
+    if (u > kLatentWaves) return false;
+    // dL/dz: K = d_m in parts of a multiple of 4, at most 32 (registers), one per wave
+    for (L.q4_kper = 4; L.q4_kper <= 32; L.q4_kper += 4) {
+        u = 0;
+        for (int j = 0; j < st.num_jobs; ++j) u += cdiv(mdl.input_dim[st.job_mod[j]], L.q4_kper);
+        if (u <= kLatentWaves) break;
+    }
+    if (L.q4_kper > 32) return false;
+    u = 0;
+    for (int j = 0; j <= MOPOE_MAX_JOBS; ++j) {
+        L.q4_begin[j] = u;
+        if (j < st.num_jobs) {
+            if (z_dim(mdl, st.job_mod[j]) > 64) return false;   // one 64-column tile of g_z
+            u += cdiv(mdl.input_dim[st.job_mod[j]], L.q4_kper);
+        }
+    }
+    // heads: (tile of 64 columns, K part) units per present modality; K = 256 = 64 groups
+    // of 4, cut in as many parts as the waves allow (at most 16 groups per part: registers)
+    L.wf = wfrag_layout(mdl);
+    int tiles1 = 0;
+    for (int i = 0; i < mdl.num_mods; ++i)
+        if ((st.present_mask >> i) & 1) tiles1 += L.wf.t1[i];
+    if (tiles1 < 1 || tiles1 > kLatentWaves) return false;
+    L.q1_parts = kLatentWaves / tiles1;
+    if (L.q1_parts > 8) L.q1_parts = 8;
+    L.q1_kper = cdiv(kHid / 4, L.q1_parts);
+    if (L.q1_kper > 16) return false;
+    u = 0, pm = 0;
+    for (int i = 0; i < mdl.num_mods; ++i)
+        if ((st.present_mask >> i) & 1) {
+            L.q1_begin[pm++] = u;
+            u += L.wf.t1[i] * L.q1_parts;
+            if (heads_dim(mdl, i) > 128) return false;   // (the reduce pass: 128 columns per modality)
+        }
+    for (int i = pm; i <= MOPOE_MAX_MODS; ++i) L.q1_begin[i] = u;
+    // decoder: one 64-column tile per wave, K = z_dim <= 64
+    u = 0;
+    for (int j = 0; j <= MOPOE_MAX_JOBS; ++j) {
+        L.q3_begin[j] = u;
+        if (j < st.num_jobs) u += L.wf.t3[st.job_mod[j]];
+    }
+    if (u > kLatentWaves) return false;
+    L.kl_first = u < kLatentWaves ? u : 0;   // the KL sums ride on the decoder stage's idle waves
+    L.kl_pool = kLatentWaves - L.kl_first;
+    L.qred = L.total;
+    // the decoder weights' LDS copy (dL/dz) lies behind the 64-column partials of the heads
+    // and dL/dz stages, inside / past the area of dL/dh's 256-column partials (used later)
+    int off = L.qred + kLatentWaves * 4 * 64, units = 0;
+    L.wd_units[0] = L.wd_units[1] = L.wd_valid[0] = L.wd_valid[1] = 0;
+    pm = 0;
+    for (int i = 0; i < mdl.num_mods; ++i) {
+        L.wdl[i] = off;
+        if (!((st.present_mask >> i) & 1)) continue;
+        // (32 rows from the start of the last K part: dL/dz reads them unguarded, as zeros; the
+        //  piece that holds the weights' last words is completed with the parameters behind
+        //  them -- finite, and multiplied by the zero padding of the g_xhat tile)
+        const int d = mdl.input_dim[i], zd = z_dim(mdl, i);
+        const int nu = cdiv(((cdiv(d, L.q4_kper) - 1) * L.q4_kper + 32) * zd, 256);
+        L.wd_valid[pm] = cdiv(d * zd, 4);
+        L.wd_units[pm++] = nu;
+        units += nu;
+        off += 256 * nu;
+    }
+    for (int i = mdl.num_mods; i < MOPOE_MAX_MODS; ++i) L.wdl[i] = off;
+    if (units > 6 * kLatentWaves) return false;   // (six units per wave)
+    for (int w = 0; w < kLatentWaves; ++w) {
+        LatentLds::Q4Unit& q = L.q4u[w];
+        memset(&q, 0, sizeof(q));
+        q.nk4 = -1;
+        if (w >= L.q4_begin[st.num_jobs]) continue;
+        int j = 0;
+        while (w >= L.q4_begin[j + 1]) ++j;
+        const int m = st.job_mod[j], k0 = (w - L.q4_begin[j]) * L.q4_kper;
+        const int left = round_up(mdl.input_dim[m], 16) - k0;   // columns of the g_xhat tile that are its own
+        q.nk4 = left <= 0 ? 0 : cdiv(left, 4) < L.q4_kper / 4 ? cdiv(left, 4) : L.q4_kper / 4;
+        q.ga = L.dj[j].gx + k0;
+        q.wl = L.wdl[m] + k0 * z_dim(mdl, m);
+        q.ldx_zd = L.dj[j].ldx << 8 | z_dim(mdl, m);   // (z_dim <= 64: checked above)
+    }
+    L.total = L.qred + kLatentWaves * 4 * 256;
+    if (off > L.total) L.total = off;
+    return L.total * 4 <= 160 * 1024;
+}
+
+void step_layout(const mopoe_model& mdl, const mopoe_step& st, LatentLds& L) {
+    L.quad_ok = 0;
+    if (quad_step(mdl, st)) {
+        L.fits = latent_lds_layout_rows(mdl, st, kLatentWaves, 4, L);
+        if (L.fits && L.xs_early && L.single_pass && L.s3_nt == 2 && quad_tables(mdl, st, L)) {
+            L.quad_ok = 1;
+            return;
+        }
+    }
+    latent_lds_layout(mdl, st, kLatentWaves, L);
+    L.quad_ok = 0;
+    L.wf = wfrag_layout(mdl);
+}
+
 int latent_lds_bytes(const mopoe_model& mdl, const mopoe_step& st) {
     LatentLds L;
-    latent_lds_layout(mdl, st, kLatentWaves, L);
+    step_layout(mdl, st, L);
     return L.total * (int)sizeof(float);
 }
 
@@ -1709,7 +1885,7 @@ int launch_form(const KArgs& ka) {
     if (getenv("MOPOE_NO_LEAN") != nullptr) return 0;
     if (!st.backward || !st.sample || st.joint_mode != MOPOE_JOINT_MIXTURE || st.group_rows != 0 ||
         L.rows != kRows)
-        return 0;
+        return 0;   // (four-row groups: the caller picks form 4)
     for (int k = 0; k < st.num_subsets; ++k)
         if (st.sub_kind[k] == MOPOE_SUB_SLICES) return 0;
     if (mdl.num_mods <= 2 && L.single_pass && L.s3_nt == 2 && L.xs_early && st.num_jobs <= 2) return 1;
@@ -1756,19 +1932,29 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     // Small training batches: encoder layer and per-sample chain in ONE launch
     // (k_fused).  Needs full 16-row groups and the whole grid resident at once to pay.
     const int row_tiles = cdiv(ka.st.n, kRows);
+    const bool quad = ka.lds.rows == 4 && ka.lds.quad_ok;
+    if (quad && !ka.buf.wfrag)
+        return fail(MOPOE_ERR_ARG, "the four-row form needs mopoe_buffers.wfrag%s");
+    const int groups = cdiv(ka.st.n, quad ? 4 : kRows);   // row groups = consumer blocks
     FHead hd;
     memset(&hd, 0, sizeof(hd));
     hd.row_tiles = row_tiles;
     hd.ks = 4;
-    int nlin = 4 * row_tiles * la.ngroups;
-    if (nlin + row_tiles > fuse_blocks()) {   // too many 64-column tiles: 256-column ones
+    hd.gpt = quad ? 4 : 1;
+    // a modality of <= 16 columns has ONE K fragment: its K parts 1.. are zeros, the unsplit
+    // form gives the same bits, and one 256-column block does for a row tile
+    auto narrow = [&](int z) { return la.g[z].K <= 16; };
+    int nlin = 0;
+    for (int z = 0; z < la.ngroups; ++z) nlin += (narrow(z) ? 1 : 4) * row_tiles;
+    if (nlin + groups > fuse_blocks()) {   // too many 64-column tiles: 256-column ones
         hd.ks = 1;
         nlin = row_tiles * la.ngroups;
     }
     int blocks_per_tile[MOPOE_MAX_MODS];
     for (int z = 0; z < MOPOE_MAX_MODS; ++z) {
-        hd.tiles[z] = hd.ks == 4 ? 4 : kLatentWaves;
-        blocks_per_tile[z] = z < la.ngroups ? (hd.ks == 4 ? 4 : 1) : 0;
+        const bool one = hd.ks != 4 || (z < la.ngroups && narrow(z));
+        hd.tiles[z] = one ? kLatentWaves : 4;
+        blocks_per_tile[z] = z < la.ngroups ? (one ? 1 : 4) : 0;
     }
     // the widest modalities get 32-column blocks while the grid still fits the chip:
     // a block's MFMA chain is its tiles x K, and the row groups wait for the slowest
@@ -1776,12 +1962,12 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         for (;;) {
             int worst = -1, cost = 0;
             for (int z = 0; z < la.ngroups; ++z)
-                if (la.g[z].K * hd.tiles[z] > cost) {
+                if (hd.tiles[z] <= 4 && la.g[z].K * hd.tiles[z] > cost) {
                     cost = la.g[z].K * hd.tiles[z];
                     worst = z;
                 }
-            if (worst < 0 || hd.tiles[worst] == 2 || la.g[worst].K < 64 ||
-                nlin + 4 * row_tiles + row_tiles > fuse_blocks())
+            if (worst < 0 || hd.tiles[worst] != 4 || la.g[worst].K < 64 ||
+                nlin + 4 * row_tiles + groups > fuse_blocks())
                 break;
             hd.tiles[worst] = 2;
             blocks_per_tile[worst] = 8;
@@ -1792,14 +1978,18 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         hd.producers += blocks_per_tile[z];
     }
     hd.nlin = nlin;
-    if (ka.lds.rows == kRows && ka.st.group_rows == 0 && nlin + row_tiles <= fuse_blocks() && !no_fuse()) {
+    la.sig_n = hd.gpt;
+    la.sig_stride = ka.lds.part_stride;
+    la.sig_groups = groups;
+    if ((ka.lds.rows == kRows || quad) && ka.st.group_rows == 0 && nlin + groups <= fuse_blocks() && !no_fuse()) {
         static thread_local int lds_opted_f = 0;
         const int kp = round_up(maxd < kEncKChunk ? maxd : kEncKChunk, 16);
-        const int lin_lds = (kRows + kRows * (kp + 4) + (hd.ks == 4 ? 4 * kRows * 68 : kRows * 260)) * (int)sizeof(float);
+        const int lin_lds = (kRows + kRows * (kp + 4) + 4 * kRows * 68) * (int)sizeof(float);   // (>= kRows * 260)
         if (lin_lds > lds) lds = lin_lds;
         if (lds > 64 * 1024 && lds > lds_opted_f) {
             const void* forms[] = {reinterpret_cast<const void*>(k_fused<0>), reinterpret_cast<const void*>(k_fused<1>),
-                                   reinterpret_cast<const void*>(k_fused<2>), reinterpret_cast<const void*>(k_fused<3>)};
+                                   reinterpret_cast<const void*>(k_fused<2>), reinterpret_cast<const void*>(k_fused<3>),
+                                   reinterpret_cast<const void*>(k_fused<4>)};
             for (const void* fn : forms) {
                 hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 if (e != hipSuccess) return fail(MOPOE_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1812,8 +2002,9 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         fa.la = la;
         {
             ProfScope ps(MOPOE_KERNEL_FUSED, s);
-            const dim3 grid(nlin + row_tiles), block(kLatentThreads);
-            switch (launch_form(ka)) {   // (the instantiations are described in latent_body)
+            const dim3 grid(nlin + groups), block(kLatentThreads);
+            switch (quad ? 4 : launch_form(ka)) {   // (the instantiations are described in latent_body)
+                case 4: hipLaunchKernelGGL(k_fused<4>, grid, block, (size_t)lds, s, fa); break;
                 case 1: hipLaunchKernelGGL(k_fused<1>, grid, block, (size_t)lds, s, fa); break;
                 case 2: hipLaunchKernelGGL(k_fused<2>, grid, block, (size_t)lds, s, fa); break;
                 case 3: hipLaunchKernelGGL(k_fused<3>, grid, block, (size_t)lds, s, fa); break;
@@ -1856,6 +2047,12 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w, const XgPeer
             {ka.buf.g_xhat[m], ka.buf.z[m], nullptr, d, d, ldz_glb(mdl, m), zd,
              njobs_m * st.n, mdl.off_wd[m], mdl.off_bd[m], 0, 0, m, njobs_m * st.n},
         };
+        const WFrag wf = wfrag_layout(mdl);
+        jobs[0].wf_off = jobs[1].wf_off = jobs[2].wf_off = -1;
+        if (ka.buf.wfrag) {
+            jobs[1].wf_off = wf.whf[m], jobs[1].wf_k4 = kHid / 4;
+            jobs[2].wf_off = wf.wdf[m], jobs[2].wf_k4 = wf.k4d[m];
+        }
         for (int k = 0; k < 3; ++k) {
             WJob& jb = jobs[k];
             jb.tiles_j = cdiv(jb.xcols + 1, 32);  // + bias column
@@ -1921,7 +2118,7 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
     bind_buffers(ka, *buf);
     ka.st.backward = 1;
     ka.st.sample = 1;
-    latent_lds_layout(ka.mdl, ka.st, kLatentWaves, ka.lds);
+    step_layout(ka.mdl, ka.st, ka.lds);
     latent_bind(ka.lds, ka.buf);
     hipStream_t s = static_cast<hipStream_t>(stream);
     WArgs w;
@@ -1951,6 +2148,13 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
         }
     }
     return check_launch("k_wgrad");
+}
+
+int launch_wfrag(const mopoe_model& mdl, const mopoe_buffers& buf, hipStream_t s) {
+    const int pieces = wfrag_layout(mdl).total / 4;
+    hipLaunchKernelGGL(k_wfrag, dim3(cdiv(pieces, 256) < 256 ? cdiv(pieces, 256) : 256), dim3(256), 0, s, mdl,
+                       buf.params, buf.wfrag);
+    return check_launch("k_wfrag");
 }
 
 }  // namespace
@@ -2026,6 +2230,7 @@ int mopoe_sizeof(int which) {
         case 6: return (int)offsetof(mopoe_buffers, partials);
         case 8: return (int)offsetof(mopoe_buffers, status_host);
         case 9: return (int)offsetof(mopoe_model, off_ctrl);
+        case 10: return (int)offsetof(mopoe_buffers, wfrag);
         case 7: return (int)offsetof(mopoe_model, num_floats);
         default: return -1;
     }
@@ -2034,8 +2239,12 @@ int mopoe_sizeof(int which) {
 int mopoe_ldz(const mopoe_model* mdl, int mod) { return ldz_glb(*mdl, mod); }
 
 int mopoe_partials_stride(const mopoe_model* mdl) { return partials_stride(*mdl); }
+int mopoe_wfrag_floats(const mopoe_model* mdl) { return mdl ? wfrag_layout(*mdl).total : 0; }
 int mopoe_row_groups(const mopoe_model* mdl, const mopoe_step* st) {
-    return mdl && st && st->n > 0 ? latent_groups(*mdl, *st, kLatentWaves) : 0;
+    if (!mdl || !st || st->n < 1) return 0;
+    LatentLds L;
+    step_layout(*mdl, *st, L);
+    return cdiv(st->n, L.rows);
 }
 
 int mopoe_latent_lds_bytes(const mopoe_model* mdl, const mopoe_step* st) {
@@ -2050,7 +2259,7 @@ int mopoe_forward(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buff
     ka.st = *st;
     bind_buffers(ka, *buf);
     ka.st.backward = 0;
-    latent_lds_layout(ka.mdl, ka.st, kLatentWaves, ka.lds);
+    step_layout(ka.mdl, ka.st, ka.lds);
     latent_bind(ka.lds, ka.buf);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = launch_forward_part(ka, nullptr, s)) return rc;
@@ -2078,7 +2287,13 @@ int mopoe_adam_step(const mopoe_model* mdl, int32_t present_mask, const mopoe_bu
         hipLaunchKernelGGL(k_adam, dim3(128, sg.nseg), dim3(256), 0,
                            static_cast<hipStream_t>(stream), *buf, sg);
     }
-    return check_launch("k_adam");
+    if (int rc = check_launch("k_adam")) return rc;
+    return buf->wfrag ? launch_wfrag(*mdl, *buf, static_cast<hipStream_t>(stream)) : 0;
+}
+
+int mopoe_wfrag_refresh(const mopoe_model* mdl, const mopoe_buffers* buf, void* stream) {
+    if (!mdl || !buf || !buf->params || !buf->wfrag) return fail(MOPOE_ERR_ARG, "mopoe_wfrag_refresh: null argument%s");
+    return launch_wfrag(*mdl, *buf, static_cast<hipStream_t>(stream));
 }
 
 int mopoe_linear(const float* x, int32_t n, int32_t k, const float* w, const float* b,
@@ -2230,7 +2445,8 @@ int mopoe_comm_allreduce_adam(mopoe_comm* c, const mopoe_model* mdl, int32_t pre
         return fail(MOPOE_ERR_ARG, "communicator was created for another buffer length%s");
     AdamSegs sg;
     if (int rc = build_adam_segs(*mdl, present_mask, *adam, c->world, sg)) return rc;
-    return comm_launch(c, buf->grads, buf, &sg, static_cast<hipStream_t>(stream));
+    if (int rc = comm_launch(c, buf->grads, buf, &sg, static_cast<hipStream_t>(stream))) return rc;
+    return buf->wfrag ? launch_wfrag(*mdl, *buf, static_cast<hipStream_t>(stream)) : 0;
 }
 
 int mopoe_comm_train_step(mopoe_comm* c, const mopoe_model* mdl, const mopoe_step* st,

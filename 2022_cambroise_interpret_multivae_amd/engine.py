@@ -65,6 +65,10 @@ class MoPoEEngine:
         self.grads = torch.zeros(P, **f)
         self.exp_avg = torch.zeros(P, **f)
         self.exp_avg_sq = torch.zeros(P, **f)
+        # fragment-major copies of the head / decoder weights for the four-row form of the
+        # fused launch: kept by the library's own updates, rebuilt here after other writers
+        self.wfrag = torch.zeros(L.lib.mopoe_wfrag_floats(spec.c_model), **f)
+        self._wfrag_version = -1
         self.counters = torch.zeros(L.COUNTERS_ALLOC, dtype=torch.int32, device=self.device)
         # pinned host mirror {steps done, invalid} the last kernel of every training step
         # writes: an invalid step is noticed without synchronising (check_valid)
@@ -153,6 +157,30 @@ class MoPoEEngine:
             self._ws[key] = ws
         return ws
 
+    def refresh_wfrag(self):
+        """mopoe_wfrag_refresh: the fragment-major weight copies from `params`.  Runs by
+        itself whenever torch has seen a write to the flat buffer or a view of it
+        (tensor._version); call it after writes torch does not count (`.data`, raw
+        pointers)."""
+        b = L.Buffers()
+        b.params = L.ptr(self.params)
+        b.wfrag = L.ptr(self.wfrag)
+        L.check(L.lib.mopoe_wfrag_refresh(self.spec.c_model, b, L.stream_ptr()),
+                "mopoe_wfrag_refresh")
+        self._wfrag_version = self.params._version
+
+    def _optim_buffers(self, b):
+        if self._on_gpu and self.params._version != self._wfrag_version:
+            self.refresh_wfrag()
+        b.params = L.ptr(self.params)
+        b.grads = L.ptr(self.grads)
+        b.exp_avg = L.ptr(self.exp_avg)
+        b.exp_avg_sq = L.ptr(self.exp_avg_sq)
+        b.counters = L.ptr(self.counters)
+        b.status_host = L.ptr(self.status_host)
+        b.wfrag = L.ptr(self.wfrag)
+        return b
+
     def _buffers(self, ws, x, row_index, stats_host=None, plan=None):
         b = L.Buffers()
         if plan is not None:
@@ -162,12 +190,7 @@ class MoPoEEngine:
                 raise ValueError("stats_host must be a pinned float32 tensor of >= %d"
                                  % L.NUM_STATS)
             b.stats_host = L.ptr(stats_host)
-        b.params = L.ptr(self.params)
-        b.grads = L.ptr(self.grads)
-        b.exp_avg = L.ptr(self.exp_avg)
-        b.exp_avg_sq = L.ptr(self.exp_avg_sq)
-        b.counters = L.ptr(self.counters)
-        b.status_host = L.ptr(self.status_host)
+        self._optim_buffers(b)
         for m, name in enumerate(self.spec.names):
             if name in x:
                 b.x[m] = L.ptr(x[name])
@@ -307,13 +330,7 @@ class MoPoEEngine:
         L.require_gpu()
         if present_mask is None:
             present_mask = self.last_present_mask
-        b = L.Buffers()
-        b.params = L.ptr(self.params)
-        b.grads = L.ptr(self.grads)
-        b.exp_avg = L.ptr(self.exp_avg)
-        b.exp_avg_sq = L.ptr(self.exp_avg_sq)
-        b.counters = L.ptr(self.counters)
-        b.status_host = L.ptr(self.status_host)
+        b = self._optim_buffers(L.Buffers())
         L.check(L.lib.mopoe_adam_step(self.spec.c_model, present_mask, b,
                                       C.byref(self.adam), int(world), L.stream_ptr()),
                 "mopoe_adam_step")

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 6
+#define MOPOE_ABI_VERSION 7
 #define MOPOE_MAX_MODS 5      /* modalities                                   */
 #define MOPOE_MAX_SUBSETS 31  /* 2^MAX_MODS - 1 non-empty subsets             */
 #define MOPOE_MAX_JOBS 10     /* decoder passes: 1 joint + 1 unimodal per mod */
@@ -231,6 +231,15 @@ typedef struct mopoe_buffers {
     float* g_xhat[MOPOE_MAX_MODS];       /* (R_m, d_m)   d loss / d loc        */
     float* g_heads[MOPOE_MAX_MODS];      /* (n, nh_m)                          */
     float* g_pre[MOPOE_MAX_MODS];        /* (n, 256)     d loss / d pre-relu   */
+    float* wfrag;                        /* optional, mopoe_wfrag_floats(model) floats:
+                                            fragment-major copies of the head and decoder
+                                            weights, read by the four-row form of the
+                                            fused launch (NULL: that form is not used).
+                                            Every update this library applies keeps them
+                                            in step with `params`; after ANY other write
+                                            to `params` (initialisation, a checkpoint, a
+                                            broadcast) call mopoe_wfrag_refresh before
+                                            the next step                            */
     float* partials;                     /* (mopoe_row_groups(model, step),
                                             mopoe_partials_stride(model)); ZERO it
                                             once after allocating: one word of a
@@ -269,6 +278,10 @@ int mopoe_sizeof(int which);
 
 /* leading dimension (floats) of z[m]: round_up(zd_m, 4) */
 int mopoe_ldz(const mopoe_model* model, int mod);
+/* floats of mopoe_buffers.wfrag */
+int mopoe_wfrag_floats(const mopoe_model* model);
+/* rebuild buffers.wfrag from buffers.params (see mopoe_buffers.wfrag) */
+int mopoe_wfrag_refresh(const mopoe_model* model, const mopoe_buffers* buf, void* stream);
 /* floats per row group in `partials` */
 int mopoe_partials_stride(const mopoe_model* model);
 /* row groups the fused per-sample kernel cuts the batch into for this step

@@ -13,6 +13,16 @@ from hip_util import Report, TOL, compare_forward, make_engine
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["four_rows", "sixteen_rows"])
+def row_groups_form(request, monkeypatch):
+    """Every case under both forms of the fused launch: the four-row groups small batches
+    of <= 2 modalities get by default, and (MOPOE_QUAD=0) the 16-row groups."""
+    if request.param == "sixteen_rows":
+        monkeypatch.setenv("MOPOE_QUAD", "0")
+    else:
+        monkeypatch.delenv("MOPOE_QUAD", raising=False)
+
+
 @pytest.mark.parametrize("case", case_names())
 def test_train_steps_match_oracle(case):
     fx = Fixture(case)

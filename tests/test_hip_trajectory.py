@@ -20,6 +20,16 @@ from hip_util import Report, make_engine
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["four_rows", "sixteen_rows"])
+def row_groups_form(request, monkeypatch):
+    """Every case under both forms of the fused launch: the four-row groups small batches
+    of <= 2 modalities get by default, and (MOPOE_QUAD=0) the 16-row groups."""
+    if request.param == "sixteen_rows":
+        monkeypatch.setenv("MOPOE_QUAD", "0")
+    else:
+        monkeypatch.delenv("MOPOE_QUAD", raising=False)
+
 CASES = {
     # configs[1] / C1: 2-modality joint_elbo, dims 7+444, latent 20, batch 256
     "C1_joint_elbo_bs256": dict(names=["clinical", "rois"], dims=[7, 444], style=[3, 20],

@@ -44,6 +44,8 @@ def run(mask):
 full = run(0)
 print("k_fused, all phases (HIP events, incl. ~2 us of event overhead): %.2f us" % full)
 for i, name in enumerate(PHASES):
+    if os.environ.get("KNOCK_SHORT"):
+        break
     t = run(1 << i)
     print("  without %-24s %6.2f us   (%+.2f)" % (name, t, t - full))
 allk = run((1 << len(PHASES)) - 1)
@@ -57,5 +59,13 @@ for label, mask in (("no producers (row groups in full)", 1 << 14 | 1),
                     ("neither (the bare launch of 224 workgroups)", 1 << 14 | 1 << 15)):
     t = run(mask)
     print("  %-46s %6.2f us   (%+.2f)" % (label, t, t - full))
+if os.environ.get("MOPOE_QUAD") == "1":
+    for label, mask in (("S4: no Wd reads", 1 << 17), ("S4: no MFMAs", 1 << 18),
+                        ("S4: no partial stores", 1 << 19), ("S3: no global stores", 1 << 20),
+                        ("S0: no Wd -> LDS requests", 1 << 16),
+                        ("S4: scalar scaffolding only", 1 << 17 | 1 << 18 | 1 << 19),
+                        ("S4 out", 1 << 8), ("S4 + 3 dependent scalar loads", 1 << 21)):
+        t = run(mask)
+        print("  %-46s %6.2f us   (%+.2f)" % (label, t, t - full))
 again = run(0)
 print("k_fused, all phases again: %.2f us" % again)

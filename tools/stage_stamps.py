@@ -39,12 +39,19 @@ for it in range(40):
     x = torch.stack([raw[12] - raw[4], raw[13] - raw[12], raw[14] - raw[13],
                      raw[6] - raw[14]]) % 4294967296.0
     inner = x if it == 0 else inner + x
+    x4 = torch.stack([raw[12] - raw[6], raw[13] - raw[12], raw[14] - raw[13],
+                      raw[7] - raw[14]]) % 4294967296.0
+    inner4 = x4 if it == 0 else inner4 + x4
 acc /= 40
 inner /= 40
+inner4 /= 40
 print("k_latent stage times, %s, N=%d (block 0)" % (method, n))
 for nme, row in zip(names, acc):
     rt, mt = row[0].item(), row[1].item()
     print("%-22s %6.2f us   clock %5.0f MHz" % (nme, rt / 100.0, (mt / rt * 100.0) if rt else 0))
 print("%-22s %6.2f us" % ("total", acc[:, 0].sum().item() / 100.0))
+if os.environ.get("MOPOE_QUAD") == "1":
+    print("(four-row form) inside S4, wave 0: scalar set-up %.2f | reads + MFMAs %.2f | partial stores %.2f | "
+          "to the barrier's end %.2f us" % tuple(inner4[:, 0] / 100.0))
 print("inside S3 (wave 8): loads+MFMA issue %.2f | four rows of epilogue %.2f | sums %.2f | "
       "waiting at the barrier %.2f us" % tuple(inner[:, 0] / 100.0))
