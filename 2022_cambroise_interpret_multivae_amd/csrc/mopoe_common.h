@@ -591,6 +591,17 @@ DEV int find_seg(const int (&begin)[NSEG + 1], int u) {
     for (int i = 1; i < NSEG; ++i) k += u >= begin[i];
     return k;
 }
+// The same with u >= begin[i] taken as the sign bit of begin[i] - u - 1: plain integer
+// arithmetic stays on the scalar unit (the bool-to-int of a compare goes through v_cndmask +
+// readfirstlane).  Used by the four-row form; in the 16-row forms it moved the register
+// allocation to a slower place (+0.75 us, same box), so they keep the form above.
+template <int NSEG>
+DEV int find_seg_s(const int (&begin)[NSEG + 1], int u) {
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < NSEG; ++i) k += (int)((uint32_t)(begin[i] - u - 1) >> 31);
+    return k;
+}
 
 // Sum over the 64 lanes, the same value in every lane.  Inside a 16-lane row with DPP
 // adds (quad swaps, then the two row mirrors: an instruction each, no LDS crossbar --
