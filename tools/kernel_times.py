@@ -32,7 +32,7 @@ def run(method, n, fused, names=("clinical", "rois"), dims=(7, 444), steps=300):
           flush=True)
 
 
-if __name__ == "__main__" and "--fwd" not in sys.argv:
+if __name__ == "__main__" and "--fwd" not in sys.argv and "--none" not in sys.argv:
     run("joint_elbo", 256, True)
     run("joint_elbo", 256, False)
     run("joint_elbo", 1024, True)

@@ -6,7 +6,7 @@ Uses the -DMOPOE_KNOCK build (make -C .../csrc knock): MOPOE_KNOCK is a bit mask
 phases of a row group that are left out; the launch is timed with HIP events, phase by
 phase, and the difference to the full launch is that phase's share of the critical
 path.  Results of such launches are garbage (no update is applied); only time counts.
-    python tools/knockout.py [N]"""
+    python tools/knockout.py [N] [C1|C3|C5]      (bench.py's configurations)"""
 import os
 import sys
 
@@ -15,11 +15,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import mopoe_amd as mm  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-spec = mm.ModelSpec(["clinical", "rois"], [7, 444], [3, 20], method="joint_elbo")
+import bench  # noqa: E402  (the configurations)
+
+cfg = bench.CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "C1"]
+n = int(sys.argv[1]) if len(sys.argv) > 1 and int(sys.argv[1]) > 0 else cfg["batch"]
+spec = bench.make_spec(cfg)
 g = torch.Generator().manual_seed(0)
-pool = [{"clinical": torch.randn(n, 7, generator=g).cuda(),
-         "rois": torch.randn(n, 444, generator=g).cuda()} for _ in range(16)]
+pool = [{k: torch.randn(n, d, generator=g).cuda() for k, d in zip(cfg["names"], cfg["dims"])}
+        for _ in range(16)]
+STEPS = int(os.environ.get("KNOCK_STEPS", "1500"))
 PHASES = ["wait for the producers", "noise", "x tiles", "h -> LDS", "S1 heads MFMA",
           "S2b fusion fwd", "S3 decoder units", "KL sums", "S4 g_z", "S5 fusion bwd",
           "S6 g_pre", "LDS zeroing", "heads W prefetch", "kernarg prefetch"]
@@ -33,7 +37,7 @@ def run(mask):
         eng.train_step(pool[i % 16])
     torch.cuda.synchronize()
     mm._lib.profile_enable(True)
-    for i in range(1500):
+    for i in range(STEPS):
         eng.train_step(pool[i % 16])
     torch.cuda.synchronize()
     prof = mm._lib.profile_read()
@@ -43,11 +47,16 @@ def run(mask):
 
 full = run(0)
 print("k_fused, all phases (HIP events, incl. ~2 us of event overhead): %.2f us" % full)
+ONLY = [int(v) for v in os.environ.get("KNOCK_ONLY", "").split(",") if v]   # phase numbers
 for i, name in enumerate(PHASES):
     if os.environ.get("KNOCK_SHORT"):
         break
+    if ONLY and i not in ONLY:
+        continue
     t = run(1 << i)
     print("  without %-24s %6.2f us   (%+.2f)" % (name, t, t - full))
+if ONLY:
+    sys.exit(0)
 allk = run((1 << len(PHASES)) - 1)
 print("  without all of them             %6.2f us   (%+.2f)" % (allk, allk - full))
 fwd = run(sum(1 << i for i in (4, 5, 6, 7, 8, 9, 10)))
