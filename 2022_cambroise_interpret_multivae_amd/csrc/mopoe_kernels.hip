@@ -812,27 +812,24 @@ __global__ __launch_bounds__(kLatentThreads) void k_fused(const FArgs f_by_value
         const int z = find_seg<MOPOE_MAX_MODS>(hd.begin, b);
         const int local = b - hd.begin[z];
         const int stride = f.ka.lds.part_stride;
-        const int ks = hd.ks & 0xFF;
-        if (ks == 4 && hd.tiles[z] == kLatentWaves) {   // K <= 16: one 256-column block
+        const int tl = hd.tiles[z];   // 16-column tiles per block: 16 (one 256-column block), 8, 4 or 2
+        if (tl == kLatentWaves) {     // K <= 16, or a grid that only fits with one block per row tile
             const int rt = local;
             int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * hd.gpt * stride + kHandoffWord);
             linear_block16<1>(a, a.g[z], lds, rt, 0, tid, lane, wave, flag, z);
-        } else if (ks == 4) {
-            const int two = hd.tiles[z] == 2;
-            const int ncg = two ? 8 : 4;
+        } else {
+            const int ncg = kLatentWaves / tl;
             // (An XCD-aware map of the (row tile, column group) grid -- 4 x 2 over the classes
             //  b % 8 -- takes 0.45 MB of counted fetch off the launch and costs 0.15 us, the
             //  next kernel then finding its operands in other XCDs' L2s: measured, not kept.)
             const int cg = local % ncg, rt = local / ncg;
             int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * hd.gpt * stride + kHandoffWord);
-            if (two)
+            if (tl == 2)
                 linear_block16<4, 2>(a, a.g[z], lds, rt, cg, tid, lane, wave, flag, z);
-            else
+            else if (tl == 4)
                 linear_block16<4, 4>(a, a.g[z], lds, rt, cg, tid, lane, wave, flag, z);
-        } else {
-            const int rt = local;
-            int32_t* flag = reinterpret_cast<int32_t*>(f.ka.buf.partials + (size_t)rt * hd.gpt * stride + kHandoffWord);
-            linear_block16<1>(a, a.g[z], lds, rt, 0, tid, lane, wave, flag, z);
+            else   // 128-column blocks, K over two waves (mid-size batches)
+                linear_block16<2, 8>(a, a.g[z], lds, rt, cg, tid, lane, wave, flag, z);
         }
         asm volatile("" ::"s"(karg_sink));
         return;
@@ -972,6 +969,10 @@ struct WJob {
     int32_t mod;           // modality of the parameters (its own Adam step count)
     int32_t xtotal;        // rows of X (the descriptor covers exactly xtotal * ldx floats)
     int32_t wf_off, wf_k4; // fragment-major copy of this weight (WFrag): float offset or -1, K/4
+    int32_t th;            // output rows per tile: 32, or 16 for a job with twice the batch rows of
+                           // the others (method poe's decoder: joint + unimodal pass) -- a block's
+                           // time is its MFMA count, rows x tile area, and the launch is as long as
+                           // its longest block
 };
 
 struct WArgs {
@@ -995,15 +996,16 @@ struct WArgs {
 //   B fragments  X[r][j0 + 2c + tj]   -> output columns j = j0 + 2c + tj
 // (column-interleaved 16x16 tiles, as in k_latent).  The bias gradient is the
 // column of an implicit all-ones feature at j == xcols.
-template <bool GATHER, int STEPS>  // STEPS MFMA steps (4 batch rows each) per round: 16 or 8
+// TI = 1: a 16-row tile -- one A fragment, G[r][i0 + c] -> output rows i = i0 + 4q' + reg.
+template <bool GATHER, int STEPS, int TI>  // STEPS MFMA steps (4 batch rows each) per round: 16 or 8
 DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int ldg_, int ldx,
                     int gcols, int xcols, int i0, int j0, int rbeg, int rend, int lane,
                     f32x4 (&acc)[2][2]) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int c = lane & 15, q = lane >> 4;
-    const int ci = i0 + 2 * c, cj = j0 + 2 * c;
+    const int ci = i0 + TI * c, cj = j0 + 2 * c;
     // per-element validity of the two columns this lane reads (bit masks)
-    const uint32_t am0 = ci < gcols ? 0xFFFFFFFFu : 0u, am1 = ci + 1 < gcols ? 0xFFFFFFFFu : 0u;
+    const uint32_t am0 = ci < gcols ? 0xFFFFFFFFu : 0u, am1 = ((TI == 2) & (ci + 1 < gcols)) ? 0xFFFFFFFFu : 0u;
     const uint32_t bm0 = cj < xcols ? 0xFFFFFFFFu : 0u, bm1 = cj + 1 < xcols ? 0xFFFFFFFFu : 0u;
     const float one0 = cj == xcols ? 1.f : 0.f, one1 = cj + 1 == xcols ? 1.f : 0.f;
     for (int rb = rbeg; rb < rend; rb += 4 * STEPS) {
@@ -1018,8 +1020,13 @@ DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int
         for (int s = 0; s < STEPS; ++s) {
             const int r = rb + 4 * s + q;
             const bool rv = r < rend;
-            av[s] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                        gr, guard((uint32_t)(r * ldg_ + ci) * 4u, rv & (ci < gcols)), 0, 0));
+            if constexpr (TI == 2) {
+                av[s] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                            gr, guard((uint32_t)(r * ldg_ + ci) * 4u, rv & (ci < gcols)), 0, 0));
+            } else {
+                av[s][0] = ldg(gr, guard((uint32_t)(r * ldg_ + ci) * 4u, rv & (ci < gcols)));
+                av[s][1] = 0.f;
+            }
             bv[s] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
                         xr, guard((uint32_t)(xrow[s] * ldx + cj) * 4u, rv & (cj < xcols)), 0, 0));
         }
@@ -1036,8 +1043,10 @@ DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int
                 __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, b1) & bm1) + (rv ? one1 : 0.f);
             acc[0][0] = mfma_16x16x4(fa0, fb0, acc[0][0]);
             acc[0][1] = mfma_16x16x4(fa0, fb1, acc[0][1]);
-            acc[1][0] = mfma_16x16x4(fa1, fb0, acc[1][0]);
-            acc[1][1] = mfma_16x16x4(fa1, fb1, acc[1][1]);
+            if constexpr (TI == 2) {
+                acc[1][0] = mfma_16x16x4(fa1, fb0, acc[1][0]);
+                acc[1][1] = mfma_16x16x4(fa1, fb1, acc[1][1]);
+            }
         }
     }
 }
@@ -1084,14 +1093,16 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         for (int k = 1; k < 3 * MOPOE_MAX_MODS; ++k) ji += (k < w.njobs) & (b >= w.tile_begin[k]);
         const WJob& job = w.jobs[ji];
         const int t = b - job.tile_begin;
-        const int i0 = (t / job.tiles_j) * 32, j0 = (t % job.tiles_j) * 32;
+        const int th = job.th;   // (wave-uniform: 32 or 16)
+        const int i0 = (t / job.tiles_j) * th, j0 = (t % job.tiles_j) * 32;
         const int R = job.R, gcols = job.gcols, xcols = job.xcols;
 
         // epilogue ownership: thread -> output row i0 + tid/8, columns j0 + 4*(tid%8) ..+3
         const bool epi = tid < 256;  // the first four waves own the 32x32 outputs
         const int ei = i0 + ((tid & 255) >> 3), ej = j0 + 4 * (tid & 7);
-        const int nvalid = (epi & (ei < gcols)) ? min(xcols - ej, 4) : 0;   // weight columns
-        const bool has_b = epi & (ei < gcols) & (xcols >= ej) & (xcols < ej + 4) & (job.off_b >= 0);
+        const bool erow = epi & (ei < gcols) & (ei < i0 + th);
+        const int nvalid = erow ? min(xcols - ej, 4) : 0;   // weight columns
+        const bool has_b = erow & (xcols >= ej) & (xcols < ej + 4) & (job.off_b >= 0);
         const int widx = job.off_w + ei * xcols + ej;
         const int bidx = job.off_b + ei;
         const size_t pbytes = (size_t)a.mdl.num_floats * sizeof(float);
@@ -1125,32 +1136,40 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         // rounds of 64 batch rows (32 loads in flight), or of 32 when a wave's share is
         // no more than that (the padded steps of a long round would still issue MFMAs)
         const bool half = rq <= 32;
-        if (job.xrows) {
+        if (th == 16) {   // (only non-gathered operands: the decoder's z and g_xhat)
             if (half)
-                wgrad_rows<true, 8>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                    rbeg, rend, lane, acc);
+                wgrad_rows<false, 8, 1>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                        rbeg, rend, lane, acc);
             else
-                wgrad_rows<true, 16>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                     rbeg, rend, lane, acc);
+                wgrad_rows<false, 16, 1>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                         rbeg, rend, lane, acc);
+        } else if (job.xrows) {
+            if (half)
+                wgrad_rows<true, 8, 2>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                       rbeg, rend, lane, acc);
+            else
+                wgrad_rows<true, 16, 2>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                        rbeg, rend, lane, acc);
         } else {
             if (half)
-                wgrad_rows<false, 8>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                     rbeg, rend, lane, acc);
+                wgrad_rows<false, 8, 2>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                        rbeg, rend, lane, acc);
             else
-                wgrad_rows<false, 16>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                      rbeg, rend, lane, acc);
+                wgrad_rows<false, 16, 2>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                         rbeg, rend, lane, acc);
         }
         GSTAMP(buf.stats, kStampBase + 42, stamp_blk);
         // this wave's partial block -> LDS as [i][j]
         {
             const int c = lane & 15, q = lane >> 4;
+            const int rs = th == 16 ? 1 : 2;   // (a 16-row tile: the first fragment's rows, packed)
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                 for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        blk[wave][(2 * (4 * q + r) + ti) * kWgLd + 2 * c + tj] = acc[ti][tj][r];
+                        if (ti < rs) blk[wave][(rs * (4 * q + r) + ti) * kWgLd + 2 * c + tj] = acc[ti][tj][r];
         }
         __syncthreads();
         // fixed-order sum of the four partials, 4 consecutive columns per thread
@@ -1835,7 +1854,9 @@ int latent_lds_bytes(const mopoe_model& mdl, const mopoe_step& st) {
     return L.total * (int)sizeof(float);
 }
 
-int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s) {
+// ks_hint: the K split of the fused launch for the same step (its sums must come out the
+// same whichever form runs: tests/test_hip_fused.py), or 0 for this launch's own choice
+int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s, int ks_hint = 0) {
     LinArgs la = la_in;
     const int kp = round_up(max_k < kEncKChunk ? max_k : kEncKChunk, 16);
     const size_t lds = ((size_t)kRows * (kp + 4) + kLinRedFloats) * sizeof(float);
@@ -1850,6 +1871,7 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s) 
     const int tiles = cdiv(la.n, kRows) * la.ngroups;
     int ks = 1;
     while (ks < 4 && tiles * cdiv(max_cols, 64 / ks) < 2 * 256) ks *= 2;
+    if (ks_hint) ks = ks_hint;
     la.ksplit = ks;
     {
         ProfScope ps(MOPOE_KERNEL_LINEAR, s);
@@ -1944,17 +1966,21 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     // a modality of <= 16 columns has ONE K fragment: its K parts 1.. are zeros, the unsplit
     // form gives the same bits, and one 256-column block does for a row tile
     auto narrow = [&](int z) { return la.g[z].K <= 16; };
-    int nlin = 0;
-    for (int z = 0; z < la.ngroups; ++z) nlin += (narrow(z) ? 1 : 4) * row_tiles;
-    if (nlin + groups > fuse_blocks()) {   // too many 64-column tiles: 256-column ones
-        hd.ks = 1;
-        nlin = row_tiles * la.ngroups;
-    }
+    // K parts (= column groups per row tile) of the wide modalities: as many as the chip
+    // holds at once -- 4 x 64 columns, 2 x 128 (a block's MFMA chain is its tiles x K: twice
+    // the blocks, half the chain), or one 256-column block
+    auto nlin_for = [&](int ks) {
+        int n = 0;
+        for (int z = 0; z < la.ngroups; ++z) n += (narrow(z) ? 1 : ks) * row_tiles;
+        return n;
+    };
+    while (hd.ks > 1 && nlin_for(hd.ks) + groups > fuse_blocks()) hd.ks /= 2;
+    int nlin = nlin_for(hd.ks);
     int blocks_per_tile[MOPOE_MAX_MODS];
     for (int z = 0; z < MOPOE_MAX_MODS; ++z) {
-        const bool one = hd.ks != 4 || (z < la.ngroups && narrow(z));
-        hd.tiles[z] = one ? kLatentWaves : 4;
-        blocks_per_tile[z] = z < la.ngroups ? (one ? 1 : 4) : 0;
+        const bool one = hd.ks == 1 || (z < la.ngroups && narrow(z));
+        hd.tiles[z] = one ? kLatentWaves : kLatentWaves / hd.ks;
+        blocks_per_tile[z] = z < la.ngroups ? (one ? 1 : hd.ks) : 0;
     }
     // the widest modalities get 32-column blocks while the grid still fits the chip:
     // a block's MFMA chain is its tiles x K, and the row groups wait for the slowest
@@ -2013,7 +2039,9 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         }
         return check_launch("k_fused");
     }
-    if (int rc = launch_linear(la, maxd, kHid, s)) return rc;
+    // (a step the fused launch could take, kept in three launches: the fused form's K split)
+    const bool fusable = (ka.lds.rows == kRows || quad) && ka.st.group_rows == 0 && nlin + groups <= fuse_blocks();
+    if (int rc = launch_linear(la, maxd, kHid, s, fusable ? hd.ks : 0)) return rc;
 
     static thread_local int lds_opted = 0;
     if (lds > 64 * 1024 && lds > lds_opted) {
@@ -2056,9 +2084,11 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w, const XgPeer
         for (int k = 0; k < 3; ++k) {
             WJob& jb = jobs[k];
             jb.tiles_j = cdiv(jb.xcols + 1, 32);  // + bias column
+            // (a job over at least twice the step's batch rows: 16-row tiles, see WJob::th)
+            jb.th = (k == 2 && jb.R >= 2 * st.n && !getenv("MOPOE_WGRAD_TALL")) ? 16 : 32;
             jb.tile_begin = tile;
             w.tile_begin[w.njobs] = tile;
-            tile += cdiv(jb.gcols, 32) * jb.tiles_j;
+            tile += cdiv(jb.gcols, jb.th) * jb.tiles_j;
             w.jobs[w.njobs++] = jb;
         }
     }
