@@ -1431,6 +1431,15 @@ struct AdamSegs {
     int32_t off_ctrl;     // control words of the gradient buffer (mopoe_model.off_ctrl)
     float grad_scale;     // 1 / world
     mopoe_adam adam;
+    // the weight matrix inside segment k that has a fragment-major copy (WFrag: the heads
+    // matrix of an encoder segment, the decoder matrix of a decoder segment): the update
+    // stores the copy too, as the Adam epilogue of k_wgrad does -- no k_wfrag launch behind it
+    int32_t wf_src[2 * MOPOE_MAX_MODS];    // first float of the matrix in the flat buffer, -1: no copy
+    int32_t wf_count[2 * MOPOE_MAX_MODS];  // its floats
+    int32_t wf_k[2 * MOPOE_MAX_MODS];      // row length K
+    int32_t wf_k4[2 * MOPOE_MAX_MODS];     // pieces per row of the copy
+    int32_t wf_dst[2 * MOPOE_MAX_MODS];    // the copy's first float in buffers.wfrag
+    int32_t wf_total;                      // floats of buffers.wfrag
 };
 
 // Whether the step may be applied: no sticky invalid word, and (data-parallel) every
@@ -1474,15 +1483,61 @@ __global__ __launch_bounds__(256) void k_adam(const mopoe_buffers buf, const Ada
     __syncthreads();
     const AdamCoef ac = sc;
     const bool valid = ok != 0;
-    const int beg = s.begin[blockIdx.y], end = s.end[blockIdx.y];
-    if (valid)
-        for (int i = beg + blockIdx.x * blockDim.x + threadIdx.x; i < end;
-             i += gridDim.x * blockDim.x) {
-            // a multiply of its own (never contracted into the update), as in k_xgmi
-            const float g = __fmul_rn(buf.grads[i], s.grad_scale);
-            adam_update(ac, g, buf.params[i], buf.exp_avg[i], buf.exp_avg_sq[i], buf.params + i,
-                        buf.exp_avg + i, buf.exp_avg_sq + i);
+    const int beg = s.begin[blockIdx.y], end = s.end[blockIdx.y];   // (beg: 256-byte aligned)
+    const int wsrc = s.wf_src[blockIdx.y], wcnt = s.wf_count[blockIdx.y], wk = s.wf_k[blockIdx.y];
+    const int wk4 = s.wf_k4[blockIdx.y], wdst = s.wf_dst[blockIdx.y];
+    const bool wcopy = buf.wfrag != nullptr && wsrc >= 0;
+    if (valid) {
+        const size_t pbytes = (size_t)end * sizeof(float);
+        const rsrc_t rp = make_rsrc(buf.params, pbytes), rm = make_rsrc(buf.exp_avg, pbytes);
+        const rsrc_t rv = make_rsrc(buf.exp_avg_sq, pbytes), rg = make_rsrc(buf.grads, pbytes);
+        const rsrc_t rf = make_rsrc(buf.wfrag, wcopy ? (size_t)s.wf_total * sizeof(float) : 0);
+        // four consecutive floats per thread (16-byte accesses; the words a load takes past
+        // `end` come back as zeros and are not stored)
+        for (int i = beg + 4 * (blockIdx.x * blockDim.x + threadIdx.x); i < end;
+             i += 4 * gridDim.x * blockDim.x) {
+            const uint32_t o = (uint32_t)i * 4u;
+            const f32x4 g4 = ldg4(rg, o), p4 = ldg4(rp, o), m4 = ldg4(rm, o), v4 = ldg4(rv, o);
+            f32x4 np, nm, nv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // a multiply of its own (never contracted into the update), as in k_xgmi
+                float po, mo, vo;
+                adam_update(ac, __fmul_rn(g4[e], s.grad_scale), p4[e], m4[e], v4[e], &po, &mo, &vo);
+                np[e] = po;
+                nm[e] = mo;
+                nv[e] = vo;
+            }
+            if (i + 4 <= end) {
+                stg4(rp, o, np);
+                stg4(rm, o, nm);
+                stg4(rv, o, nv);
+            } else {
+                for (int e = 0; i + e < end; ++e) {
+                    buf.params[i + e] = np[e];
+                    buf.exp_avg[i + e] = nm[e];
+                    buf.exp_avg_sq[i + e] = nv[e];
+                }
+            }
+            if (wcopy) {
+                const int rel = i - wsrc;
+                if ((wk & 3) == 0) {   // the four floats are one piece of the copy
+                    if (rel >= 0 && rel < wcnt) {
+                        const int r = rel / wk, k = rel - r * wk;
+                        stg4(rf, (uint32_t)(wdst + wfrag_piece(r, k >> 2, wk4)) * 4u, np);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int q = rel + e;
+                        const int r = q / wk, k = q - r * wk;
+                        stg1(rf, guard((uint32_t)(wdst + wfrag_piece(r, k >> 2, wk4) + (k & 3)) * 4u,
+                                       (q >= 0) & (q < wcnt)), np[e]);
+                    }
+                }
+            }
         }
+    }
     adam_kernel_end(buf, s, valid, gridDim.x * gridDim.y, threadIdx.x);
 }
 
@@ -2109,13 +2164,25 @@ int build_adam_segs(const mopoe_model& mdl, int32_t present_mask, const mopoe_ad
                     int32_t world, AdamSegs& sg) {
     memset(&sg, 0, sizeof(sg));
     if (world < 1) return fail(MOPOE_ERR_ARG, "world must be >= 1%s");
+    const WFrag wf = wfrag_layout(mdl);
+    sg.wf_total = wf.total;
     for (int m = 0; m < mdl.num_mods; ++m) {
         if (!((present_mask >> m) & 1)) continue;
         sg.seg_mod[sg.nseg] = m;
         sg.begin[sg.nseg] = mdl.off_w1[m];
+        sg.wf_src[sg.nseg] = mdl.off_wh[m];
+        sg.wf_count[sg.nseg] = heads_dim(mdl, m) * kHid;
+        sg.wf_k[sg.nseg] = kHid;
+        sg.wf_k4[sg.nseg] = kHid / 4;
+        sg.wf_dst[sg.nseg] = wf.whf[m];
         sg.end[sg.nseg++] = mdl.off_bh[m] + heads_dim(mdl, m);
         sg.seg_mod[sg.nseg] = m;
         sg.begin[sg.nseg] = mdl.off_wd[m];
+        sg.wf_src[sg.nseg] = mdl.off_wd[m];
+        sg.wf_count[sg.nseg] = mdl.input_dim[m] * z_dim(mdl, m);
+        sg.wf_k[sg.nseg] = z_dim(mdl, m);
+        sg.wf_k4[sg.nseg] = wf.k4d[m];
+        sg.wf_dst[sg.nseg] = wf.wdf[m];
         sg.end[sg.nseg++] = mdl.learn_output_scale ? mdl.off_lvo[m] + mdl.input_dim[m]
                                                    : mdl.off_bd[m] + mdl.input_dim[m];
     }
@@ -2314,11 +2381,10 @@ int mopoe_adam_step(const mopoe_model* mdl, int32_t present_mask, const mopoe_bu
     if (int rc = build_adam_segs(*mdl, present_mask, *adam, world, sg)) return rc;
     {
         ProfScope ps(MOPOE_KERNEL_ADAM, static_cast<hipStream_t>(stream));
-        hipLaunchKernelGGL(k_adam, dim3(128, sg.nseg), dim3(256), 0,
+        hipLaunchKernelGGL(k_adam, dim3(64, sg.nseg), dim3(256), 0,
                            static_cast<hipStream_t>(stream), *buf, sg);
     }
-    if (int rc = check_launch("k_adam")) return rc;
-    return buf->wfrag ? launch_wfrag(*mdl, *buf, static_cast<hipStream_t>(stream)) : 0;
+    return check_launch("k_adam");   // (the fragment-major weight copies included)
 }
 
 int mopoe_wfrag_refresh(const mopoe_model* mdl, const mopoe_buffers* buf, void* stream) {
