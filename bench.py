@@ -30,6 +30,7 @@ Prints ONE JSON line (rank 0).  Besides the contract's keys:
   cpu_baseline   the CPU oracle (oracle/mopoe_oracle.py, a PyTorch-CPU restatement of the
                  reference step) on this box's host cores: all cores and 1 thread
   cold_start     the first of the two timings (see above)
+  long_run       the --settle steps between the two, timed as one region
   other_configs  BASELINE.json configs[2] (method poe, batch 1024) and configs[4]
                  (4 modalities, 15 subsets, batch 512) on one GPU: samples/s + roofline
   regime_n65536  the kernels at 65,536 rows, where the batch term dominates
@@ -541,8 +542,9 @@ def main():
     def measure():
         dt0, _ = timed(args.warmup, args.steps)
         cold["dt"] = dt0
-        for i in range(SETTLE):
-            step(args.warmup + args.steps + i)
+        # (the settling steps are timed as one region too: `long_run` -- what a K of thousands
+        #  reads; a 20-step region of 0.7 ms carries its two synchronisations, ~80 us)
+        cold["settle_dt"], _ = timed(0, SETTLE, first=args.warmup + args.steps)
         return timed(args.warmup, args.steps, first=args.warmup + args.steps + SETTLE)
 
     dt, ws = measure()
@@ -569,9 +571,9 @@ def main():
             eng.exp_avg_sq.zero_()
             dt, ws = measure()
     if dist is not None:
-        t = torch.tensor([dt, cold["dt"]], device=device, dtype=torch.float64)
+        t = torch.tensor([dt, cold["dt"], cold["settle_dt"]], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, cold["dt"] = float(t[0].item()), float(t[1].item())
+        dt, cold["dt"], cold["settle_dt"] = (float(v) for v in t.tolist())
     loss = float(ws.stats[0].item())
     eng.check_valid(sync=True)     # (raises if any step of the timed region was invalid)
     if dist is not None:           # replicas must still be identical
@@ -620,6 +622,12 @@ def main():
                                "the process (idle clocks, cold caches); `value` is timed after "
                                "%d more untimed steps" % SETTLE},
     }
+    if SETTLE > 0:
+        out["long_run"] = {"steps": SETTLE, "ms_per_step": round(1e3 * cold["settle_dt"] / SETTLE, 5),
+                           "value": round(BATCH * world * SETTLE / cold["settle_dt"], 1),
+                           "unit": "samples/s",
+                           "what": "the settling steps timed as one region (same loop, same "
+                                   "barriers): the figure a K of thousands reads"}
 
     nxt = 2 * (args.warmup + args.steps) + SETTLE
     if rank == 0 and not args.no_roofline:
