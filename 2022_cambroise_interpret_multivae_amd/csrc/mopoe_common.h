@@ -607,6 +607,12 @@ DEV int find_seg_s(const int (&begin)[NSEG + 1], int u) {
 // adds (quad swaps, then the two row mirrors: an instruction each, no LDS crossbar --
 // six dependent ds_bpermute round trips cost ~500 cycles of a wave's chain), then the
 // four row sums through readlane in a fixed order.
+// float add onto an LDS word (ds_add_f32, nothing returned)
+DEV void lds_add(float* p, float v) {
+    typedef __attribute__((address_space(3))) float lds_float;
+    __hip_atomic_fetch_add((lds_float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 DEV float wave_sum(float v) {
     auto dpp_add = [](float x, auto ctrl) __attribute__((always_inline)) {
         constexpr int kCtrl = decltype(ctrl)::value;

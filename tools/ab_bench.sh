@@ -7,8 +7,8 @@ rounds=${ROUNDS:-3}
 steps=${STEPS:-3000}
 for r in $(seq $rounds); do
   for lib in "$@"; do
-    out=$(MOPOE_LIB=$lib python3 bench.py --steps $steps --warmup 300 --no-cpu-baseline --quick 2>/dev/null)
-    ms=$(echo "$out" | grep -o '"ms_per_step": [0-9.]*' | cut -d' ' -f2)
+    out=$(MOPOE_LIB=$lib python3 bench.py --steps $steps --warmup 300 --no-cpu-baseline --quick --settle 300 2>/dev/null)
+    ms=$(echo "$out" | grep -o '"ms_per_step": [0-9.]*' | head -1 | cut -d' ' -f2)
     ks=$(echo "$out" | grep -o '"kernels_avg_us": {[^}]*}')
     echo "round $r $lib ms_per_step $ms $ks"
   done
