@@ -1054,8 +1054,8 @@ DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int
 constexpr int kWgLd = 36;  // leading dim of a 32x32 partial block in LDS
 
 // kWgWaves waves split the batch rows of a block: 8 for large batches (twice as fast at
-// N >= 1024), 4 for small ones (at N = 256 the longer reduction and the larger
-// workgroups cost more than the shorter MFMA chains save).
+// N >= 1024) and from 256 rows on when every block has a CU to itself, 4 otherwise (the
+// launch code decides).
 //
 // XG (data-parallel replicas, mopoe_comm_train_step): between the block's gradient and
 // its Adam update sits the exchange of mopoe_xgmi.inc, per block: the 32x32 block (and
@@ -2232,7 +2232,10 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
     }
     {
         ProfScope ps(MOPOE_KERNEL_WGRAD, s);
-        if (ka.st.n > 512) {
+        // eight waves per block (half the MFMA chain per wave) for large batches, and from 256
+        // rows on while every block still has a CU of its own (two 512-thread blocks do not
+        // fit one: registers) -- measured: configs[1] -0.8 us, configs[4] (277 blocks) +2 us
+        if (ka.st.n > 512 || (ka.st.n >= 256 && grid.x <= 256)) {
             if (comm)
                 hipLaunchKernelGGL((k_wgrad<8, true>), grid, dim3(512), 0, s, ka, w);
             else
