@@ -38,6 +38,7 @@ class Workspace:
         self._stride = L.lib.mopoe_partials_stride(spec.c_model)
         self.partials = torch.zeros((n + L.ROWS - 1) // L.ROWS, self._stride, **f)
         self.backward = backward
+        self._cbuf = self._cbuf_partials = None   # the engine's cached mopoe_buffers
         if backward:
             self.g_xhat = [torch.empty(slots * n, spec.input_dim[m], **f)
                            for m in range(M)]
@@ -182,35 +183,51 @@ class MoPoEEngine:
         return b
 
     def _buffers(self, ws, x, row_index, stats_host=None, plan=None):
-        b = L.Buffers()
+        """The call's `mopoe_buffers`.  Everything that belongs to the workspace or the
+        optimiser is filled in once per workspace (some thirty pointers); a call only sets
+        its inputs, gather indices and the pinned log slot."""
         if plan is not None:
             ws.ensure_partials(plan.row_groups())
+        b = ws._cbuf
+        if b is None or ws._cbuf_partials is not ws.partials:
+            b = L.Buffers()
+            for m in range(self.spec.num_mods):
+                b.hidden[m] = L.ptr(ws.hidden[m])
+                b.heads[m] = L.ptr(ws.heads[m])
+                b.z[m] = L.ptr(ws.z[m])
+                b.loc[m] = L.ptr(ws.loc[m])
+                if ws.backward:
+                    b.g_xhat[m] = L.ptr(ws.g_xhat[m])
+                    b.g_heads[m] = L.ptr(ws.g_heads[m])
+                    b.g_pre[m] = L.ptr(ws.g_pre[m])
+            b.subsets_mu = L.ptr(ws.subsets_mu)
+            b.subsets_logvar = L.ptr(ws.subsets_logvar)
+            b.joint_mu = L.ptr(ws.joint_mu)
+            b.joint_logvar = L.ptr(ws.joint_logvar)
+            b.stats = L.ptr(ws.stats)
+            b.partials = L.ptr(ws.partials)
+            self._optim_buffers(b)
+            ws._cbuf, ws._cbuf_partials = b, ws.partials
+        elif self._on_gpu and self.params._version != self._wfrag_version:
+            self.refresh_wfrag()
         if stats_host is not None:
             if not stats_host.is_pinned() or stats_host.numel() < L.NUM_STATS:
                 raise ValueError("stats_host must be a pinned float32 tensor of >= %d"
                                  % L.NUM_STATS)
             b.stats_host = L.ptr(stats_host)
-        self._optim_buffers(b)
+        else:
+            b.stats_host = None
         for m, name in enumerate(self.spec.names):
-            if name in x:
-                b.x[m] = L.ptr(x[name])
-                b.x_rows[m] = x[name].shape[0]
-                if row_index is not None and row_index.get(name) is not None:
-                    b.row_index[m] = L.ptr(row_index[name])
-            b.hidden[m] = L.ptr(ws.hidden[m])
-            b.heads[m] = L.ptr(ws.heads[m])
-            b.z[m] = L.ptr(ws.z[m])
-            b.loc[m] = L.ptr(ws.loc[m])
-            if ws.backward:
-                b.g_xhat[m] = L.ptr(ws.g_xhat[m])
-                b.g_heads[m] = L.ptr(ws.g_heads[m])
-                b.g_pre[m] = L.ptr(ws.g_pre[m])
-        b.subsets_mu = L.ptr(ws.subsets_mu)
-        b.subsets_logvar = L.ptr(ws.subsets_logvar)
-        b.joint_mu = L.ptr(ws.joint_mu)
-        b.joint_logvar = L.ptr(ws.joint_logvar)
-        b.stats = L.ptr(ws.stats)
-        b.partials = L.ptr(ws.partials)
+            t = x.get(name)
+            if t is not None:
+                b.x[m] = L.ptr(t)
+                b.x_rows[m] = t.shape[0]
+                ri = row_index.get(name) if row_index is not None else None
+                b.row_index[m] = L.ptr(ri) if ri is not None else None
+            else:
+                b.x[m] = None
+                b.x_rows[m] = 0
+                b.row_index[m] = None
         return b
 
     def _prepare(self, batch, row_index):
@@ -246,9 +263,12 @@ class MoPoEEngine:
     def _bind_noise(self, plan, step, eps):
         """Point the step at injected eps tensors (reference draw order)."""
         keep = []
+        if eps is None and not getattr(plan, "_eps_bound", False):
+            return keep          # (nothing bound since the plan was made: nothing to clear)
         for j in range(L.MAX_JOBS):
             step.job_eps_content[j] = None
             step.job_eps_style[j] = None
+        plan._eps_bound = eps is not None
         if eps is None:
             return keep
         if len(eps) != len(plan.noise_slots):
