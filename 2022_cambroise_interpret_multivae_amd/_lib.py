@@ -13,12 +13,13 @@ MAX_SUBSETS = 31
 MAX_JOBS = 10
 HIDDEN = 256
 ROWS = 16
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_RANKS = 8
 IPC_HANDLE_BYTES = 64
 
 SUB_POE, SUB_POE_PRIOR, SUB_SLICES = 0, 1, 2
 JOINT_MIXTURE, JOINT_MEAN, JOINT_EXPERT = 0, 1, 2
+LIKELIHOODS = {"normal": 0, "laplace": 1}      # MOPOE_LIK_*
 
 STAT_TOTAL_LOSS = 0
 STAT_JOINT_DIV = 1
@@ -87,6 +88,7 @@ class Step(C.Structure):
         ("job_src", _i32 * MAX_JOBS),
         ("job_stream", _i32 * MAX_JOBS),
         ("job_nll_coef", _f32 * MAX_JOBS),
+        ("likelihood", _i32),
         ("job_eps_content", _ptr * MAX_JOBS),
         ("job_eps_style", _ptr * MAX_JOBS),
         ("seed", C.c_uint64),

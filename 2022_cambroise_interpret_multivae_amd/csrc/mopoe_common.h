@@ -613,6 +613,9 @@ DEV void lds_add(float* p, float v) {
     __hip_atomic_fetch_add((lds_float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// torch's sign(): 0 at 0 (the gradient torch.abs hands back)
+DEV float sign_of(float v) { return v > 0.f ? 1.f : v < 0.f ? -1.f : 0.f; }
+
 DEV float wave_sum(float v) {
     auto dpp_add = [](float x, auto ctrl) __attribute__((always_inline)) {
         constexpr int kCtrl = decltype(ctrl)::value;

@@ -30,6 +30,7 @@ namespace {
 constexpr int kLatentThreads = 1024;
 constexpr int kLatentWaves = kLatentThreads / kWave;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+constexpr float kLog2 = 0.69314718055994530942f;
 constexpr float kPoeEps = 1e-8f;
 constexpr int kHandoffSpins = 1 << 18;  // bounded wait of a consumer group (~0.3 s)
 constexpr int kStampWord = 80;          // (diagnostic build) unused words of a wave's LDS slot
@@ -1685,6 +1686,8 @@ int validate(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* 
     if (mdl->class_dim < 1 || mdl->class_dim > 256)
         return fail(MOPOE_ERR_ARG, "class_dim out of range%s");
     if (st->n < 1) return fail(MOPOE_ERR_ARG, "empty batch%s");
+    if (st->likelihood != MOPOE_LIK_NORMAL && st->likelihood != MOPOE_LIK_LAPLACE)
+        return fail(MOPOE_ERR_ARG, "likelihood must be MOPOE_LIK_NORMAL or MOPOE_LIK_LAPLACE%s");
     if (st->present_mask <= 0 || st->present_mask >= (1 << mdl->num_mods))
         return fail(MOPOE_ERR_ARG, "present_mask out of range%s");
     if (st->num_subsets < 1 || st->num_subsets > MOPOE_MAX_SUBSETS)
@@ -1783,7 +1786,8 @@ bool quad_step(const mopoe_model& mdl, const mopoe_step& st) {
     const char* v = getenv("MOPOE_QUAD");
     if (v && atoi(v) == 0) return false;
     if (!st.backward || !st.sample || st.joint_mode != MOPOE_JOINT_MIXTURE || st.group_rows != 0 ||
-        st.rows_per_group != 0 || mdl.num_mods > 2 || st.num_jobs > 2 || st.n > 256 || st.n < 4)
+        st.rows_per_group != 0 || mdl.num_mods > 2 || st.num_jobs > 2 || st.n > 256 || st.n < 4 ||
+        st.likelihood != MOPOE_LIK_NORMAL)
         return false;
     for (int k = 0; k < st.num_subsets; ++k)
         if (st.sub_kind[k] == MOPOE_SUB_SLICES) return false;
@@ -1961,7 +1965,7 @@ int launch_form(const KArgs& ka) {
     const LatentLds& L = ka.lds;
     if (getenv("MOPOE_NO_LEAN") != nullptr) return 0;
     if (!st.backward || !st.sample || st.joint_mode != MOPOE_JOINT_MIXTURE || st.group_rows != 0 ||
-        L.rows != kRows)
+        L.rows != kRows || st.likelihood != MOPOE_LIK_NORMAL)
         return 0;   // (four-row groups: the caller picks form 4)
     for (int k = 0; k < st.num_subsets; ++k)
         if (st.sub_kind[k] == MOPOE_SUB_SLICES) return 0;

@@ -421,8 +421,9 @@ class MoPoEEngine:
         for m, name in enumerate(spec.names):
             if name in plan.present:
                 scale = (self.views["decoders.%s.logvar" % name] * 0.5).exp()
-                rec[name] = torch.distributions.Normal(
-                    ws.loc[m][:n], scale, validate_args=False)
+                lik = torch.distributions.Laplace if spec.likelihood == "laplace" \
+                    else torch.distributions.Normal      # (modalities/modality.py:18-30)
+                rec[name] = lik(ws.loc[m][:n], scale, validate_args=False)
         res["rec"] = rec
         return res
 

@@ -29,7 +29,8 @@ class ModelSpec:
                  method="joint_elbo", factorized=True, beta=1.0,
                  beta_style=1.0, beta_content=1.0, initial_out_logvar=-3.0,
                  learn_output_scale=True, lr=0.002, betas=(0.9, 0.999),
-                 adam_eps=1e-8, rec_weights=None, poe_unimodal_elbos=True):
+                 adam_eps=1e-8, rec_weights=None, poe_unimodal_elbos=True,
+                 likelihood="normal"):
         if method not in METHODS:
             raise NotImplementedError(
                 "method %r: only joint_elbo / poe / moe are on the MI355X hot "
@@ -60,6 +61,13 @@ class ModelSpec:
         # run_epochs.py:115: method poe adds the unimodal ELBOs (one extra forward per
         # modality) only when this flag is set
         self.poe_unimodal_elbos = bool(poe_unimodal_elbos)
+        # modalities/modality.py:18-30: what the decoder's (loc, scale) pair parameterises.
+        # Normal and Laplace take that pair; Bernoulli / OneHotCategorical do not
+        if likelihood not in L.LIKELIHOODS:
+            raise NotImplementedError(
+                "likelihood %r: the decoder's (loc, scale) output feeds Normal or Laplace"
+                % (likelihood,))
+        self.likelihood = likelihood
         self.rec_weights = dict(rec_weights) if rec_weights else \
             {n: 1.0 for n in self.names}
 
@@ -94,8 +102,6 @@ class ModelSpec:
                 "hidden encoder layer, no hidden decoder layer")
         if getattr(flags, "learn_output_sample_scale", False):
             raise NotImplementedError("learn_output_sample_scale")
-        if getattr(flags, "likelihood", "normal") != "normal":
-            raise NotImplementedError("only the normal likelihood is fused")
         if getattr(flags, "dropout_rate", 0.0) != 0.0:
             raise NotImplementedError("dropout_rate != 0")
         method = ("poe" if flags.modality_poe else
@@ -110,7 +116,8 @@ class ModelSpec:
                    lr=getattr(flags, "initial_learning_rate", 0.002),
                    betas=(getattr(flags, "beta_1", 0.9),
                           getattr(flags, "beta_2", 0.999)),
-                   poe_unimodal_elbos=getattr(flags, "poe_unimodal_elbos", True))
+                   poe_unimodal_elbos=getattr(flags, "poe_unimodal_elbos", True),
+                   likelihood=getattr(flags, "likelihood", "normal"))
 
     @property
     def num_mods(self):
@@ -220,6 +227,7 @@ class StepPlan:
         st.rows_per_group = L.rows_per_group()
         st.group_rows = int(group_rows)
         st.num_subsets = len(spec.subset_keys)
+        st.likelihood = L.LIKELIHOODS[spec.likelihood]
 
         # subsets (BaseMMVae.inference :190-216)
         self.avail_keys = []

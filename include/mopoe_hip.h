@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 7
+#define MOPOE_ABI_VERSION 8
 #define MOPOE_MAX_MODS 5      /* modalities                                   */
 #define MOPOE_MAX_SUBSETS 31  /* 2^MAX_MODS - 1 non-empty subsets             */
 #define MOPOE_MAX_JOBS 10     /* decoder passes: 1 joint + 1 unimodal per mod */
@@ -47,6 +47,8 @@ extern "C" {
 #define MOPOE_SUB_SLICES 2     /* moe_fusion: contiguous row slices of members */
 
 /* joint_mode: BaseMMVae.inference (utils/BaseMMVae.py:226-231) */
+#define MOPOE_LIK_NORMAL 0     /* torch.distributions.Normal(loc, scale)       */
+#define MOPOE_LIK_LAPLACE 1    /* torch.distributions.Laplace(loc, scale)      */
 #define MOPOE_JOINT_MIXTURE 0  /* sample=True: mixture_component_selection     */
 #define MOPOE_JOINT_MEAN 1     /* sample=False: mean of mus and of logvars     */
 #define MOPOE_JOINT_EXPERT 2   /* use_expert=<subset key>                      */
@@ -179,6 +181,9 @@ typedef struct mopoe_step {
     int32_t job_stream[MOPOE_MAX_JOBS];    /* pass id, non-decreasing; jobs of
                                               a pass share the content eps    */
     float job_nll_coef[MOPOE_MAX_JOBS];    /* d loss / d nll(job)              */
+    int32_t likelihood;                    /* MOPOE_LIK_*: what the decoders' (loc, scale)
+                                              parameterises (modalities/modality.py:18-30,
+                                              42-45); ABI 8 -- the word was padding before   */
 
     /* noise: injected eps (parity runs) or NULL -> on-device Philox4x32-10   */
     const float* job_eps_content[MOPOE_MAX_JOBS]; /* (n, class_dim)            */

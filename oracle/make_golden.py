@@ -86,6 +86,13 @@ CASES += [
     # run_epochs.py:115: method poe without the unimodal ELBOs
     dict(case="c3_poe_nounimodal_n16", **C1, method="poe", factorized=True, N=16,
          steps=2, full=True, poe_unimodal_elbos=False),
+    # modalities/modality.py:18-30: --likelihood laplace
+    dict(case="c1_joint_laplace_n32", **C1, method="joint_elbo", factorized=True, N=32,
+         steps=3, full=True, likelihood="laplace"),
+    dict(case="c3_poe_laplace_n19", **C1, method="poe", factorized=True, N=19,
+         steps=2, full=True, likelihood="laplace"),
+    dict(case="c5_4mod_laplace_n23", **C5, method="joint_elbo", factorized=True, N=23,
+         steps=1, full=True, likelihood="laplace"),
 ]
 
 # forward-only variants (BaseMMVae.forward flags), on the c1 model
@@ -136,11 +143,13 @@ def build(ns, c, seed=0):
                           mo.Config(c["names"], c["input_dim"], c["style_dim"],
                                     factorized=c["factorized"]).style_dim,
                           method=c["method"], factorized=c["factorized"],
-                          poe_unimodal_elbos=c.get("poe_unimodal_elbos", True))
+                          poe_unimodal_elbos=c.get("poe_unimodal_elbos", True),
+                          likelihood=c.get("likelihood", "normal"))
     exp = rh.build_experiment(ns, flags, c["names"])
     cfg = mo.Config(c["names"], c["input_dim"], c["style_dim"],
                     method=c["method"], factorized=c["factorized"],
-                    poe_unimodal_elbos=c.get("poe_unimodal_elbos", True))
+                    poe_unimodal_elbos=c.get("poe_unimodal_elbos", True),
+                    likelihood=c.get("likelihood", "normal"))
     init = mo.init_params(cfg, seed)
     missing, unexpected = exp.models.load_state_dict(init, strict=True)
     assert not missing and not unexpected

@@ -37,8 +37,13 @@ class Config:
                  method="joint_elbo", factorized=True, beta=1.0,
                  beta_style=1.0, beta_content=1.0, initial_out_logvar=-3.0,
                  learn_output_scale=True, lr=0.002, betas=(0.9, 0.999),
-                 adam_eps=1e-8, poe_unimodal_elbos=True):
+                 adam_eps=1e-8, poe_unimodal_elbos=True, likelihood="normal"):
         assert method in ("joint_elbo", "poe", "moe")
+        # experiments/modalities/modality.py:18-30: the decoder's (loc, scale) pair feeds
+        # torch.distributions.Normal or Laplace (Bernoulli / OneHotCategorical take other
+        # arguments than the pair this decoder returns)
+        assert likelihood in ("normal", "laplace")
+        self.likelihood = likelihood
         self.names = list(names)
         self.input_dim = list(input_dim)
         M = len(self.names)
@@ -406,9 +411,15 @@ def normal_log_prob(loc, scale, x):
         - math.log(math.sqrt(2 * math.pi))
 
 
-def calc_log_prob(loc, scale, target, norm_value):
+def laplace_log_prob(loc, scale, x):
+    """torch.distributions.Laplace.log_prob restated."""
+    return -torch.log(2 * scale) - torch.abs(x - loc) / scale
+
+
+def calc_log_prob(loc, scale, target, norm_value, likelihood="normal"):
     """experiments/modalities/modality.py:42-45."""
-    return normal_log_prob(loc, scale, target).sum() / norm_value
+    lp = laplace_log_prob if likelihood == "laplace" else normal_log_prob
+    return lp(loc, scale, target).sum() / norm_value
 
 
 def calc_elbo(cfg, modality, recs, klds, present):
@@ -441,7 +452,7 @@ def basic_routine_epoch(params, cfg, batch, noise):
         if name in batch:
             loc, scale = results["rec"][name]
             log_probs[name] = -calc_log_prob(loc, scale, batch[name],
-                                             len(batch[name]))
+                                             len(batch[name]), cfg.likelihood)
             weighted_log_prob = weighted_log_prob + 1.0 * log_probs[name]
     group_divergence = results["joint_divergence"]
     klds = OrderedDict()
@@ -480,7 +491,7 @@ def basic_routine_epoch(params, cfg, batch, noise):
             r_mod = forward(params, cfg, {name: batch[name]}, noise)
             loc, scale = r_mod["rec"][name]
             log_prob_mod = -calc_log_prob(loc, scale, batch[name],
-                                          len(batch[name]))
+                                          len(batch[name]), cfg.likelihood)
             klds_mod = {"content": klds[name], "style": {name: kld_style_m}}
             elbos[name] = calc_elbo(cfg, name, {name: log_prob_mod}, klds_mod,
                                     batch)

@@ -105,7 +105,7 @@ def import_reference():
 def make_flags(input_dim, style_dim, class_dim=20, method="joint_elbo",
                factorized=True, beta=1.0, beta_style=1.0, beta_content=1.0,
                batch_size=256, initial_out_logvar=-3.0, learn_output_scale=True,
-               poe_unimodal_elbos=True):
+               poe_unimodal_elbos=True, likelihood="normal"):
     """SimpleNamespace mirroring what workflow.train_exp builds
     (reference experiments/workflow.py:98-145)."""
     M = len(input_dim)
@@ -119,7 +119,7 @@ def make_flags(input_dim, style_dim, class_dim=20, method="joint_elbo",
         num_hidden_layer_decoder=0, dropout_rate=0.0,
         initial_out_logvar=initial_out_logvar,
         learn_output_scale=learn_output_scale,
-        learn_output_sample_scale=False, likelihood="normal",
+        learn_output_sample_scale=False, likelihood=likelihood,
         style_dim=list(style_dim) if factorized else [0] * M,
         num_models=1, num_mods=M, device=torch.device("cpu"),
         alpha_modalities=[1.0 / (M + 1)] * (M + 1), grad_scaling=False)

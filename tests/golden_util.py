@@ -33,7 +33,8 @@ class Fixture:
         m = self.meta
         self.cfg = mo.Config(m["names"], m["input_dim"], m["style_dim"],
                              method=m["method"], factorized=m["factorized"],
-                             poe_unimodal_elbos=m.get("poe_unimodal_elbos", True))
+                             poe_unimodal_elbos=m.get("poe_unimodal_elbos", True),
+                             likelihood=m.get("likelihood", "normal"))
         self.N = m["N"]
         self.steps = m.get("steps", 1)
         self.full = m.get("full", True)

@@ -64,7 +64,8 @@ def make_engine(cfg, device="cuda"):
                         initial_out_logvar=cfg.initial_out_logvar,
                         learn_output_scale=cfg.learn_output_scale, lr=cfg.lr,
                         betas=cfg.betas, adam_eps=cfg.adam_eps,
-                        poe_unimodal_elbos=cfg.poe_unimodal_elbos)
+                        poe_unimodal_elbos=cfg.poe_unimodal_elbos,
+                        likelihood=cfg.likelihood)
     eng = mm.MoPoEEngine(spec, device)
     eng.load_params(mo.init_params(cfg, 0))
     return spec, eng

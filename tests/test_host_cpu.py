@@ -47,6 +47,28 @@ def test_descriptors_are_rejected_before_any_gpu_work():
     with pytest.raises(L.MopoeError):
         L.check(-1, "x")
     assert L.lib.mopoe_poe(None, None, 1, 1, 1e-8, None, None, None) == -1
+    bad = L.Step.from_buffer_copy(plan.c_step)
+    bad.likelihood = 7
+    assert L.lib.mopoe_forward(spec.c_model, bad, buf, None) == -1
+    assert b"likelihood" in L.lib.mopoe_last_error()
+
+
+def test_likelihood_of_the_flags_reaches_the_step():
+    """modalities/modality.py:18-30: the decoder's (loc, scale) pair parameterises Normal or
+    Laplace; the other names of the reference's switch take other arguments."""
+    import types
+    flags = types.SimpleNamespace(
+        input_dim=[7, 444], style_dim=[3, 20], class_dim=20, modality_poe=False,
+        modality_moe=False, factorized_representation=True, beta=1.0, beta_style=1.0,
+        beta_content=1.0, initial_out_logvar=-3.0, learn_output_scale=True,
+        likelihood="laplace")
+    spec = mm.ModelSpec.from_flags(flags, ["clinical", "rois"])
+    assert spec.likelihood == "laplace"
+    assert spec.plan(["clinical", "rois"], 32, backward=True).c_step.likelihood == L.LIKELIHOODS["laplace"]
+    assert mm.ModelSpec(["a"], [5], [2]).plan(["a"], 8).c_step.likelihood == L.LIKELIHOODS["normal"]
+    flags.likelihood = "bernoulli"
+    with pytest.raises(NotImplementedError):
+        mm.ModelSpec.from_flags(flags, ["clinical", "rois"])
 
 
 def test_no_cpu_fallback():
