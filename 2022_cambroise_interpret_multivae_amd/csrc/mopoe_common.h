@@ -234,9 +234,13 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
         }
     }
     L.ld_gzp = zcols + 4;
-    L.single_pass = st.num_jobs > 0 && st.job_stream[st.num_jobs - 1] == st.job_stream[0];
+    // Decoder passes = jobs with the same row block (job_slot): a modality has one job per
+    // slot, so the jobs of a slot can share the decoder stages -- method poe's unimodal jobs
+    // (one noise stream EACH, run_epochs.py:104-128) are one pass, not one per modality.
+    // (job_stream only says which jobs share their content noise.)
+    L.single_pass = st.num_jobs > 0 && st.job_slot[st.num_jobs - 1] == st.job_slot[0];
     for (int j = 0, zo = 0; j < st.num_jobs; ++j) {
-        if (j > 0 && st.job_stream[j] != st.job_stream[j - 1]) zo = 0;
+        if (j > 0 && st.job_slot[j] != st.job_slot[j - 1]) zo = 0;
         L.gz_off[j] = zo;
         zo += round_up(z_dim(m, st.job_mod[j]), 16);
     }
@@ -342,7 +346,7 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
         L.sl_begin[MOPOE_MAX_MODS] = sl;
         int widest = 0;  // 64-column decoder units of the busiest pass
         for (int j = 0, u = 0; j < st.num_jobs; ++j) {
-            if (j > 0 && st.job_stream[j] != st.job_stream[j - 1]) u = 0;
+            if (j > 0 && st.job_slot[j] != st.job_slot[j - 1]) u = 0;
             u += cdiv(m.input_dim[st.job_mod[j]], 64);
             if (u > widest) widest = u;
         }
@@ -358,7 +362,7 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
         }
         for (int j = 0; j < MOPOE_MAX_JOBS; ++j) {
             int je = j + 1;
-            while (je < st.num_jobs && st.job_stream[je] == st.job_stream[j]) ++je;
+            while (je < st.num_jobs && st.job_slot[je] == st.job_slot[j]) ++je;
             L.pass_end[j] = j < st.num_jobs ? je : j + 1;
         }
         {   // the KL sums ride on the waves the first decoder pass leaves without a unit

@@ -1736,6 +1736,12 @@ int validate(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* 
             return fail(MOPOE_ERR_ARG, "decoder job source unavailable%s");
         if (j > 0 && st->job_stream[j] < st->job_stream[j - 1])
             return fail(MOPOE_ERR_ARG, "decoder jobs must be grouped by pass%s");
+        // (the jobs of a slot share the decoder stages: one per modality, slots in order)
+        if (j > 0 && st->job_slot[j] < st->job_slot[j - 1])
+            return fail(MOPOE_ERR_ARG, "decoder jobs must be grouped by slot%s");
+        for (int i = 0; i < j; ++i)
+            if (st->job_slot[i] == st->job_slot[j] && st->job_mod[i] == m)
+                return fail(MOPOE_ERR_ARG, "two decoder jobs of one modality in one slot%s");
     }
     for (int m = 0; m < mdl->num_mods; ++m) {
         if (mdl->input_dim[m] < 1 || mdl->style_dim[m] < 0)
