@@ -1784,21 +1784,40 @@ void bind_buffers(KArgs& ka, const mopoe_buffers& buf) {
         if (!ka.buf.x_rows[m]) ka.buf.x_rows[m] = ka.st.n;
 }
 
-// Four-row groups ("quad" form of the fused launch, latent_body FORM 4): a training step of
-// <= 2 modalities with one decoder pass and at most 256 rows is cut into groups of FOUR
-// rows -- four times the row groups on four times the CUs, each issuing a quarter of the
-// MFMAs.  MOPOE_QUAD=0 turns it off.
+// Four-row groups ("quad" form of the fused launch, latent_body FORM 4 / 5): a training step of
+// <= 2 modalities with at most 256 rows is cut into groups of FOUR rows -- four times the row
+// groups on four times the CUs, each issuing a quarter of the MFMAs.
+// One decoder pass (FORM 4), or two whose jobs are the same modalities in the same order
+// (FORM 5: method poe's joint + unimodal jobs).  MOPOE_QUAD=0 turns it off.
+int quad_max_rows() {   // (MOPOE_QUAD_MAX_N: experiments)
+    const char* v = getenv("MOPOE_QUAD_MAX_N");
+    return v ? atoi(v) : 256;
+}
+int quad_first_pass_jobs(const mopoe_step& st) {   // jobs of the first decoder pass (slot)
+    int n0 = 0;
+    while (n0 < st.num_jobs && st.job_slot[n0] == st.job_slot[0]) ++n0;
+    return n0;
+}
 bool quad_step(const mopoe_model& mdl, const mopoe_step& st) {
     const char* v = getenv("MOPOE_QUAD");
     if (v && atoi(v) == 0) return false;
     if (!st.backward || !st.sample || st.joint_mode != MOPOE_JOINT_MIXTURE || st.group_rows != 0 ||
-        st.rows_per_group != 0 || mdl.num_mods > 2 || st.num_jobs > 2 || st.n > 256 || st.n < 4 ||
+        st.rows_per_group != 0 || mdl.num_mods > 2 || st.num_jobs > 4 || st.n > quad_max_rows() || st.n < 4 ||
         st.likelihood != MOPOE_LIK_NORMAL)
         return false;
     for (int k = 0; k < st.num_subsets; ++k)
         if (st.sub_kind[k] == MOPOE_SUB_SLICES) return false;
-    for (int j = 1; j < st.num_jobs; ++j)
-        if (st.job_stream[j] != st.job_stream[0]) return false;
+    {   // one pass, or two with the same modalities in the same order; the first pass samples
+        // the joint latent with one noise stream, the second one feeds each job its own subset
+        const int n0 = quad_first_pass_jobs(st);
+        if (n0 > 2 || (st.num_jobs != n0 && st.num_jobs != 2 * n0)) return false;
+        for (int j = 0; j < st.num_jobs; ++j) {
+            if (j < n0 && (st.job_stream[j] != st.job_stream[0] || st.job_src[j] >= 0)) return false;
+            if (j >= n0 && (st.job_mod[j] != st.job_mod[j - n0] || st.job_slot[j] != st.job_slot[n0] ||
+                            st.job_src[j] < 0))
+                return false;
+        }
+    }
     return getenv("MOPOE_NO_FUSE") == nullptr && getenv("MOPOE_NO_LEAN") == nullptr;
 }
 // THE layout of a step: every caller (launches, mopoe_row_groups, mopoe_latent_lds_bytes)
@@ -1816,17 +1835,19 @@ bool quad_tables(const mopoe_model& mdl, const mopoe_step& st, LatentLds& L) {
         }
     for (int i = pm; i <= MOPOE_MAX_MODS; ++i) L.q6_begin[i] = u;
     if (u > kLatentWaves) return false;
-    // dL/dz: K = d_m in parts of a multiple of 4, at most 32 (registers), one per wave
+    // dL/dz: K = d_m in parts of a multiple of 4, at most 32 (registers), one per wave.  (The
+    // tables of the K parts describe ONE pass: a second pass has the same jobs, quad_step.)
+    const int njobs0 = quad_first_pass_jobs(st);
     for (L.q4_kper = 4; L.q4_kper <= 32; L.q4_kper += 4) {
         u = 0;
-        for (int j = 0; j < st.num_jobs; ++j) u += cdiv(mdl.input_dim[st.job_mod[j]], L.q4_kper);
+        for (int j = 0; j < njobs0; ++j) u += cdiv(mdl.input_dim[st.job_mod[j]], L.q4_kper);
         if (u <= kLatentWaves) break;
     }
     if (L.q4_kper > 32) return false;
     u = 0;
     for (int j = 0; j <= MOPOE_MAX_JOBS; ++j) {
         L.q4_begin[j] = u;
-        if (j < st.num_jobs) {
+        if (j < njobs0) {
             if (z_dim(mdl, st.job_mod[j]) > 64) return false;   // one 64-column tile of g_z
             u += cdiv(mdl.input_dim[st.job_mod[j]], L.q4_kper);
         }
@@ -1850,12 +1871,13 @@ bool quad_tables(const mopoe_model& mdl, const mopoe_step& st, LatentLds& L) {
             if (heads_dim(mdl, i) > 128) return false;   // (the reduce pass: 128 columns per modality)
         }
     for (int i = pm; i <= MOPOE_MAX_MODS; ++i) L.q1_begin[i] = u;
-    // decoder: one 64-column tile per wave, K = z_dim <= 64
+    // decoder: one 64-column tile per wave, K = z_dim <= 64 (units of all passes in one table)
     u = 0;
     for (int j = 0; j <= MOPOE_MAX_JOBS; ++j) {
         L.q3_begin[j] = u;
         if (j < st.num_jobs) u += L.wf.t3[st.job_mod[j]];
     }
+    u = L.q3_begin[njobs0];                  // (units of a pass)
     if (u > kLatentWaves) return false;
     L.kl_first = u < kLatentWaves ? u : 0;   // the KL sums ride on the decoder stage's idle waves
     L.kl_pool = kLatentWaves - L.kl_first;
@@ -1884,7 +1906,7 @@ bool quad_tables(const mopoe_model& mdl, const mopoe_step& st, LatentLds& L) {
         LatentLds::Q4Unit& q = L.q4u[w];
         memset(&q, 0, sizeof(q));
         q.nk4 = -1;
-        if (w >= L.q4_begin[st.num_jobs]) continue;
+        if (w >= L.q4_begin[njobs0]) continue;
         int j = 0;
         while (w >= L.q4_begin[j + 1]) ++j;
         const int m = st.job_mod[j], k0 = (w - L.q4_begin[j]) * L.q4_kper;
@@ -1903,7 +1925,7 @@ void step_layout(const mopoe_model& mdl, const mopoe_step& st, LatentLds& L) {
     L.quad_ok = 0;
     if (quad_step(mdl, st)) {
         L.fits = latent_lds_layout_rows(mdl, st, kLatentWaves, 4, L);
-        if (L.fits && L.xs_early && L.single_pass && L.s3_nt == 2 && quad_tables(mdl, st, L)) {
+        if (L.fits && L.xs_early && L.s3_nt == 2 && quad_tables(mdl, st, L)) {
             L.quad_ok = 1;
             return;
         }
@@ -2080,7 +2102,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         if (lds > 64 * 1024 && lds > lds_opted_f) {
             const void* forms[] = {reinterpret_cast<const void*>(k_fused<0>), reinterpret_cast<const void*>(k_fused<1>),
                                    reinterpret_cast<const void*>(k_fused<2>), reinterpret_cast<const void*>(k_fused<3>),
-                                   reinterpret_cast<const void*>(k_fused<4>)};
+                                   reinterpret_cast<const void*>(k_fused<4>), reinterpret_cast<const void*>(k_fused<5>)};
             for (const void* fn : forms) {
                 hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 if (e != hipSuccess) return fail(MOPOE_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -2094,8 +2116,9 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         {
             ProfScope ps(MOPOE_KERNEL_FUSED, s);
             const dim3 grid(nlin + groups), block(kLatentThreads);
-            switch (quad ? 4 : launch_form(ka)) {   // (the instantiations are described in latent_body)
+            switch (quad ? (ka.lds.single_pass ? 4 : 5) : launch_form(ka)) {   // (the instantiations are described in latent_body)
                 case 4: hipLaunchKernelGGL(k_fused<4>, grid, block, (size_t)lds, s, fa); break;
+                case 5: hipLaunchKernelGGL(k_fused<5>, grid, block, (size_t)lds, s, fa); break;
                 case 1: hipLaunchKernelGGL(k_fused<1>, grid, block, (size_t)lds, s, fa); break;
                 case 2: hipLaunchKernelGGL(k_fused<2>, grid, block, (size_t)lds, s, fa); break;
                 case 3: hipLaunchKernelGGL(k_fused<3>, grid, block, (size_t)lds, s, fa); break;

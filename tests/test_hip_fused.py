@@ -11,8 +11,8 @@ import mopoe_amd as mm
 pytestmark = pytest.mark.gpu
 
 
-def _train(steps, seed, n=256):
-    spec = mm.ModelSpec(["clinical", "rois"], [7, 444], [3, 20])
+def _train(steps, seed, n=256, method="joint_elbo"):
+    spec = mm.ModelSpec(["clinical", "rois"], [7, 444], [3, 20], method=method)
     eng = mm.MoPoEEngine(spec, "cuda", seed=seed)
     eng.reset_parameters(torch.Generator().manual_seed(0))
     g = torch.Generator().manual_seed(1)
@@ -41,24 +41,27 @@ def test_fused_launch_is_bit_identical_to_three_launches(n, monkeypatch):
         assert torch.equal(a, c)
 
 
-@pytest.mark.parametrize("n", [256, 100, 16, 5, 4])
-def test_four_row_groups_are_deterministic_and_track_the_three_launches(n, monkeypatch):
-    """The four-row form (batches of <= 256 rows, <= 2 modalities, one decoder pass) is the
-    same step with other summation orders: bit-identical from run to run (3000 steps, no
-    hand-off times out, the fragment-major weight copies follow every update), and within
-    float32 rounding of the three-launch form while rounding has had no time to grow."""
+@pytest.mark.parametrize("n,method", [(256, "joint_elbo"), (100, "joint_elbo"), (16, "joint_elbo"),
+                                      (5, "joint_elbo"), (4, "joint_elbo"),
+                                      (256, "poe"), (37, "poe")])
+def test_four_row_groups_are_deterministic_and_track_the_three_launches(n, method, monkeypatch):
+    """The four-row form (batches of <= 256 rows, <= 2 modalities; one decoder pass, or method
+    poe's two) is the same step with other summation orders: bit-identical from run to run
+    (3000 steps, no hand-off times out, the fragment-major weight copies follow every update;
+    the two LDS adds per element of its fusion backward commute), and within float32 rounding
+    of the three-launch form while rounding has had no time to grow."""
     monkeypatch.delenv("MOPOE_NO_FUSE", raising=False)
     monkeypatch.delenv("MOPOE_QUAD", raising=False)
-    quad = _train(3000, 5, n)
-    again = _train(3000, 5, n)
+    quad = _train(3000, 5, n, method)
+    again = _train(3000, 5, n, method)
     for a, b in zip(quad, again):
         assert torch.equal(a, b)
-    short = _train(20, 5, n)
+    short = _train(20, 5, n, method)
     monkeypatch.setenv("MOPOE_QUAD", "0")
-    wide = _train(3000, 5, n)
+    wide = _train(3000, 5, n, method)
     assert not torch.equal(quad[0], wide[0]) or n > 256     # (the form under test did run)
     monkeypatch.setenv("MOPOE_NO_FUSE", "1")
-    plain = _train(20, 5, n)
+    plain = _train(20, 5, n, method)
     # 20 Adam steps of lr 1e-3 move a parameter by <= 2e-2; rounding-level differences of
     # the gradients move the two forms apart by a small fraction of that
     assert (short[0] - plain[0]).abs().max().item() < 2e-4
@@ -99,6 +102,7 @@ def test_specialised_forms_are_bit_identical_to_the_generic_one(shape, monkeypat
 
     for v in ("MOPOE_NO_LEAN", "MOPOE_NO_FUSE"):
         monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("MOPOE_QUAD", "0")   # (the 16-row instantiations; the four-row ones: above)
     special = train()
     monkeypatch.setenv("MOPOE_NO_LEAN", "1")
     generic = train()

@@ -203,6 +203,8 @@ def test_hot_kernels_keep_their_registers_and_scratch():
     assert generic["vgpr"] <= 128 and generic["scratch"] <= 128, generic
     quad = pick("k_fusedILi4EE")                         # the four-row form (the headline's launch)
     assert quad["vgpr"] <= 128 and quad["scratch"] <= 32 and quad["occupancy"] >= 4, quad
+    quad2 = pick("k_fusedILi5EE")                        # ... with method poe's second decoder pass
+    assert quad2["vgpr"] <= 128 and quad2["scratch"] <= 32 and quad2["occupancy"] >= 4, quad2
     for frag in ("k_fusedILi2EE", "k_fusedILi3EE"):      # the poe / four-modality forms
         assert pick(frag)["vgpr"] <= 128 and pick(frag)["scratch"] <= 256, (frag, pick(frag))
     assert latent["vgpr"] <= 128 and latent["scratch"] == 0, latent
