@@ -634,8 +634,14 @@ def main():
         # instrumented re-run of the same K steps: HIP events around every
         # launch, on the launch stream
         prof = profile_steps(step, nxt, args.steps)
+        # (the event overhead is what the event-timed kernels of a step sum to beyond the step
+        #  itself: the step time of the longest region timed is the one to hold them against --
+        #  a 20-step region carries 4 us per step of its two synchronisations)
+        steady = dt / args.steps
+        if SETTLE >= 10 * args.steps:
+            steady = min(steady, cold["settle_dt"] / SETTLE)
         out["roofline"] = roofline_of(spec, BATCH, prof,
-                                      dt / args.steps if (dist is None and fused) else None,
+                                      steady if (dist is None and fused) else None,
                                       fused or in_backward, world)
     elif dist is not None and not args.no_roofline:
         for i in range(args.steps):   # keep the collectives matched
