@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Soak test of the fused launch's hand-off: N training steps with and without fusion from
-the same state must end in bit-identical parameters (a stale read of h would show), and no
-hand-off may time out.  Usage: python tools/soak_fused.py [steps]"""
+"""Soak test of the fused launch's hand-off: N training steps from the same state must end in
+bit-identical parameters run to run (four-row form) and with / without fusion (16-row form: a
+stale read of h would show), and no hand-off may time out.
+Usage: python tools/soak_fused.py [steps]"""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -24,14 +25,18 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.exit(0)
 steps = sys.argv[1] if len(sys.argv) > 1 else "20000"
 out = {}
-for name, env in (("fused", {}), ("fused again", {}), ("three launches", {"MOPOE_NO_FUSE": "1"})):
+# the four-row form (default at this size) must repeat itself bit for bit; the 16-row form of
+# the fused launch and the three launches are the same arithmetic in the same order
+for name, env in (("four-row", {}), ("four-row again", {}), ("16-row fused", {"MOPOE_QUAD": "0"}),
+                  ("three launches", {"MOPOE_QUAD": "0", "MOPOE_NO_FUSE": "1"})):
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, __file__, "--child", steps], env=e, capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
     if not line:
         sys.exit("child failed:\n" + r.stdout + r.stderr)
     out[name] = line[0]
-    print("%-15s %s" % (name, line[0]))
-ok = len(set(out.values())) == 1 and out["fused"].split()[-1] == "0"
-print("bit-identical, no timeouts" if ok else "MISMATCH")
+    print("%-15s %s" % (name, line[0]), flush=True)
+ok = out["four-row"] == out["four-row again"] and out["16-row fused"] == out["three launches"] and \
+    all(v.split()[-1] == "0" for v in out.values())
+print("bit-identical pairs, no timeouts" if ok else "MISMATCH")
 sys.exit(0 if ok else 1)
