@@ -1859,7 +1859,14 @@ bool quad_tables(const mopoe_model& mdl, const mopoe_step& st, LatentLds& L) {
     for (int i = 0; i < mdl.num_mods; ++i)
         if ((st.present_mask >> i) & 1) tiles1 += L.wf.t1[i];
     if (tiles1 < 1 || tiles1 > kLatentWaves) return false;
-    L.q1_parts = kLatentWaves / tiles1;
+    {   // at least two waves of the heads stage stay free: they draw the step's noise meanwhile
+        // (measured, configs[1]: 5 K parts and one free wave +0.27 us, 4 parts and four -0.3 us
+        //  against the noise drawn in S0; MOPOE_Q1_IDLE: experiments)
+        const char* v = getenv("MOPOE_Q1_IDLE");
+        const int idle = v ? atoi(v) : 2;
+        L.q1_parts = (kLatentWaves - idle) / tiles1;
+        if (L.q1_parts < 1) L.q1_parts = kLatentWaves / tiles1;
+    }
     if (L.q1_parts > 8) L.q1_parts = 8;
     L.q1_kper = cdiv(kHid / 4, L.q1_parts);
     if (L.q1_kper > 16) return false;
