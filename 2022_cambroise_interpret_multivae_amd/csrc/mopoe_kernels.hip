@@ -970,6 +970,10 @@ struct WJob {
     int32_t mod;           // modality of the parameters (its own Adam step count)
     int32_t xtotal;        // rows of X (the descriptor covers exactly xtotal * ldx floats)
     int32_t wf_off, wf_k4; // fragment-major copy of this weight (WFrag): float offset or -1, K/4
+    int32_t fold;          // the row length is a multiple of 32: the bias gradient (column sums of G)
+                           // is added up by the lanes next to the MFMAs and parked in the spare
+                           // column of the partial tiles, instead of costing a column tile of its
+                           // own for the implicit ones column (24 of 277 blocks at configs[4])
     int32_t th;            // output rows per tile: 32, or 16 for a job with twice the batch rows of
                            // the others (method poe's decoder: joint + unimodal pass) -- a block's
                            // time is its MFMA count, rows x tile area, and the launch is as long as
@@ -1001,7 +1005,7 @@ struct WArgs {
 template <bool GATHER, int STEPS, int TI>  // STEPS MFMA steps (4 batch rows each) per round: 16 or 8
 DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int ldg_, int ldx,
                     int gcols, int xcols, int i0, int j0, int rbeg, int rend, int lane,
-                    f32x4 (&acc)[2][2]) {
+                    f32x4 (&acc)[2][2], float (&bsum)[2]) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int c = lane & 15, q = lane >> 4;
     const int ci = i0 + TI * c, cj = j0 + 2 * c;
@@ -1042,6 +1046,8 @@ DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int
                 __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, b0) & bm0) + (rv ? one0 : 0.f);
             const float fb1 =
                 __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, b1) & bm1) + (rv ? one1 : 0.f);
+            bsum[0] += fa0;   // (column sums of G: the bias gradient of a folded job; rows past the
+            bsum[1] += fa1;   //  end were read as zeros)
             acc[0][0] = mfma_16x16x4(fa0, fb0, acc[0][0]);
             acc[0][1] = mfma_16x16x4(fa0, fb1, acc[0][1]);
             if constexpr (TI == 2) {
@@ -1103,7 +1109,10 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         const int ei = i0 + ((tid & 255) >> 3), ej = j0 + 4 * (tid & 7);
         const bool erow = epi & (ei < gcols) & (ei < i0 + th);
         const int nvalid = erow ? min(xcols - ej, 4) : 0;   // weight columns
-        const bool has_b = erow & (xcols >= ej) & (xcols < ej + 4) & (job.off_b >= 0);
+        // (the bias word: with the ones column in this thread's four -- or, folded job, with
+        //  the thread that holds the row's last four weights)
+        const bool fold = job.fold != 0;
+        const bool has_b = erow & (fold ? ej + 4 == xcols : (xcols >= ej) & (xcols < ej + 4)) & (job.off_b >= 0);
         const int widx = job.off_w + ei * xcols + ej;
         const int bidx = job.off_b + ei;
         const size_t pbytes = (size_t)a.mdl.num_floats * sizeof(float);
@@ -1134,30 +1143,31 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         const rsrc_t xr = make_rsrc(job.X, (size_t)job.xtotal * job.ldx * sizeof(float));
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         f32x4 acc[2][2] = {{z4, z4}, {z4, z4}};
+        float bsum[2] = {0.f, 0.f};
         // rounds of 64 batch rows (32 loads in flight), or of 32 when a wave's share is
         // no more than that (the padded steps of a long round would still issue MFMAs)
         const bool half = rq <= 32;
         if (th == 16) {   // (only non-gathered operands: the decoder's z and g_xhat)
             if (half)
                 wgrad_rows<false, 8, 1>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                        rbeg, rend, lane, acc);
+                                        rbeg, rend, lane, acc, bsum);
             else
                 wgrad_rows<false, 16, 1>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                         rbeg, rend, lane, acc);
+                                         rbeg, rend, lane, acc, bsum);
         } else if (job.xrows) {
             if (half)
                 wgrad_rows<true, 8, 2>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                       rbeg, rend, lane, acc);
+                                       rbeg, rend, lane, acc, bsum);
             else
                 wgrad_rows<true, 16, 2>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                        rbeg, rend, lane, acc);
+                                        rbeg, rend, lane, acc, bsum);
         } else {
             if (half)
                 wgrad_rows<false, 8, 2>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                        rbeg, rend, lane, acc);
+                                        rbeg, rend, lane, acc, bsum);
             else
                 wgrad_rows<false, 16, 2>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                         rbeg, rend, lane, acc);
+                                         rbeg, rend, lane, acc, bsum);
         }
         GSTAMP(buf.stats, kStampBase + 42, stamp_blk);
         // this wave's partial block -> LDS as [i][j]
@@ -1171,6 +1181,15 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (ti < rs) blk[wave][(rs * (4 * q + r) + ti) * kWgLd + 2 * c + tj] = acc[ti][tj][r];
+            if (fold) {   // this wave's column sums of G -> the spare column 32 of its partial tile
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) {
+                    float v = bsum[ti];
+                    v += __shfl_xor(v, 16, kWave);
+                    v += __shfl_xor(v, 32, kWave);
+                    if (q == 0 && ti < rs) blk[wave][(rs * c + ti) * kWgLd + 32] = v;
+                }
+            }
         }
         __syncthreads();
         // fixed-order sum of the four partials, 4 consecutive columns per thread
@@ -1189,6 +1208,11 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         if (fuse) apply = adam_coef_resolve(acr, w.adam, ac);
         const int eb = xcols - ej;   // has_b: the bias column inside this thread's four
         float gb = eb == 0 ? g[0] : eb == 1 ? g[1] : eb == 2 ? g[2] : g[3];
+        if (fold) {   // (fixed order over the waves, as the tile)
+            gb = blk[0][li * kWgLd + 32];
+#pragma unroll
+            for (int k = 1; k < kWgWaves; ++k) gb += blk[k][li * kWgLd + 32];
+        }
         float gscale = 1.f;
         if constexpr (XG) {
             const XgPeers& x = w.xg;
@@ -2178,7 +2202,9 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w, const XgPeer
         }
         for (int k = 0; k < 3; ++k) {
             WJob& jb = jobs[k];
-            jb.tiles_j = cdiv(jb.xcols + 1, 32);  // + bias column
+            // + the bias column, unless the rows are a whole number of tiles (WJob::fold)
+            jb.fold = jb.xcols % 32 == 0 && !getenv("MOPOE_WGRAD_NOFOLD");
+            jb.tiles_j = cdiv(jb.xcols + (jb.fold ? 0 : 1), 32);
             // (a job over at least twice the step's batch rows: 16-row tiles, see WJob::th)
             jb.th = (k == 2 && jb.R >= 2 * st.n && !getenv("MOPOE_WGRAD_TALL")) ? 16 : 32;
             jb.tile_begin = tile;
