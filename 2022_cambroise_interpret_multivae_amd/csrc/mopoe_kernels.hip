@@ -1002,7 +1002,9 @@ struct WArgs {
 // (column-interleaved 16x16 tiles, as in k_latent).  The bias gradient is the
 // column of an implicit all-ones feature at j == xcols.
 // TI = 1: a 16-row tile -- one A fragment, G[r][i0 + c] -> output rows i = i0 + 4q' + reg.
-template <bool GATHER, int STEPS, int TI>  // STEPS MFMA steps (4 batch rows each) per round: 16 or 8
+// FOLD: also add up the column sums of G (WJob::fold) -- an instantiation of its own: two adds per
+// MFMA step cost the jobs that do not need them 5 % at 65,536 rows.
+template <bool GATHER, int STEPS, int TI, bool FOLD>  // STEPS MFMA steps (4 batch rows each) per round: 16 or 8
 DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int ldg_, int ldx,
                     int gcols, int xcols, int i0, int j0, int rbeg, int rend, int lane,
                     f32x4 (&acc)[2][2], float (&bsum)[2]) {
@@ -1046,8 +1048,10 @@ DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int
                 __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, b0) & bm0) + (rv ? one0 : 0.f);
             const float fb1 =
                 __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, b1) & bm1) + (rv ? one1 : 0.f);
-            bsum[0] += fa0;   // (column sums of G: the bias gradient of a folded job; rows past the
-            bsum[1] += fa1;   //  end were read as zeros)
+            if constexpr (FOLD) {
+                bsum[0] += fa0;   // (column sums of G: the bias gradient of a folded job; rows past
+                bsum[1] += fa1;   //  the end were read as zeros)
+            }
             acc[0][0] = mfma_16x16x4(fa0, fb0, acc[0][0]);
             acc[0][1] = mfma_16x16x4(fa0, fb1, acc[0][1]);
             if constexpr (TI == 2) {
@@ -1149,25 +1153,37 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         const bool half = rq <= 32;
         if (th == 16) {   // (only non-gathered operands: the decoder's z and g_xhat)
             if (half)
-                wgrad_rows<false, 8, 1>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                        rbeg, rend, lane, acc, bsum);
+                (fold ? wgrad_rows<false, 8, 1, true>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                        rbeg, rend, lane, acc, bsum)
+                      : wgrad_rows<false, 8, 1, false>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                        rbeg, rend, lane, acc, bsum));
             else
-                wgrad_rows<false, 16, 1>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                         rbeg, rend, lane, acc, bsum);
+                (fold ? wgrad_rows<false, 16, 1, true>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                         rbeg, rend, lane, acc, bsum)
+                      : wgrad_rows<false, 16, 1, false>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                         rbeg, rend, lane, acc, bsum));
         } else if (job.xrows) {
             if (half)
-                wgrad_rows<true, 8, 2>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                       rbeg, rend, lane, acc, bsum);
+                (fold ? wgrad_rows<true, 8, 2, true>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                       rbeg, rend, lane, acc, bsum)
+                      : wgrad_rows<true, 8, 2, false>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                       rbeg, rend, lane, acc, bsum));
             else
-                wgrad_rows<true, 16, 2>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                        rbeg, rend, lane, acc, bsum);
+                (fold ? wgrad_rows<true, 16, 2, true>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                        rbeg, rend, lane, acc, bsum)
+                      : wgrad_rows<true, 16, 2, false>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                        rbeg, rend, lane, acc, bsum));
         } else {
             if (half)
-                wgrad_rows<false, 8, 2>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                        rbeg, rend, lane, acc, bsum);
+                (fold ? wgrad_rows<false, 8, 2, true>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                        rbeg, rend, lane, acc, bsum)
+                      : wgrad_rows<false, 8, 2, false>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                        rbeg, rend, lane, acc, bsum));
             else
-                wgrad_rows<false, 16, 2>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                         rbeg, rend, lane, acc, bsum);
+                (fold ? wgrad_rows<false, 16, 2, true>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                         rbeg, rend, lane, acc, bsum)
+                      : wgrad_rows<false, 16, 2, false>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
+                                         rbeg, rend, lane, acc, bsum));
         }
         GSTAMP(buf.stats, kStampBase + 42, stamp_blk);
         // this wave's partial block -> LDS as [i][j]
@@ -2203,7 +2219,9 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w, const XgPeer
         for (int k = 0; k < 3; ++k) {
             WJob& jb = jobs[k];
             // + the bias column, unless the rows are a whole number of tiles (WJob::fold)
-            jb.fold = jb.xcols % 32 == 0 && !getenv("MOPOE_WGRAD_NOFOLD");
+            // (small batches only: there the count of blocks decides; with tens of thousands of
+            //  rows every block is MFMA-bound and the extra adds make the folded ones the last)
+            jb.fold = jb.xcols % 32 == 0 && st.n <= 2048 && !getenv("MOPOE_WGRAD_NOFOLD");
             jb.tiles_j = cdiv(jb.xcols + (jb.fold ? 0 : 1), 32);
             // (a job over at least twice the step's batch rows: 16-row tiles, see WJob::th)
             jb.th = (k == 2 && jb.R >= 2 * st.n && !getenv("MOPOE_WGRAD_TALL")) ? 16 : 32;
