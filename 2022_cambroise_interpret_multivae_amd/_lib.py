@@ -13,9 +13,10 @@ MAX_SUBSETS = 31
 MAX_JOBS = 10
 HIDDEN = 256
 ROWS = 16
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_RANKS = 8
 IPC_HANDLE_BYTES = 64
+RCCL_ID_BYTES = 128
 
 SUB_POE, SUB_POE_PRIOR, SUB_SLICES = 0, 1, 2
 JOINT_MIXTURE, JOINT_MEAN, JOINT_EXPERT = 0, 1, 2
@@ -31,9 +32,9 @@ NUM_STATS = STAT_LATENT_MEAN + 4 * MAX_MODS
 STATS_ALLOC = 256          # floats of a stats buffer ([128:] diagnostic stamps)
 NUM_COUNTERS = 64
 COUNTERS_ALLOC = 128       # ints of a counters buffer ([64:] diagnostic stamps)
-CTR_STEPS_BEGUN, CTR_STEPS_DONE, CTR_INVALID, CTR_ADAM_STEPS = 0, 1, 2, 4
+CTR_STEPS_BEGUN, CTR_STEPS_DONE, CTR_INVALID, CTR_FIRST_INVALID, CTR_ADAM_STEPS = 0, 1, 2, 3, 4
 KERNEL_NAMES = ("k_linear", "k_latent", "k_wgrad", "k_adam", "k_finalize", "k_fused",
-                "k_xgmi")
+                "k_xgmi", "rccl_allreduce")
 
 _i32 = C.c_int32
 _u8 = C.c_uint8
@@ -134,6 +135,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
 # every symbol include/mopoe_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "mopoe_abi_version": (C.c_int, []),
+    "mopoe_reload_knobs": (C.c_int, []),
     "mopoe_last_error": (C.c_char_p, []),
     "mopoe_sizeof": (C.c_int, [C.c_int]),
     "mopoe_profile_enable": (C.c_int, [C.c_int]),
@@ -160,6 +162,12 @@ SYMBOLS = {
                                         C.POINTER(Buffers), C.POINTER(Adam), _ptr]),
     "mopoe_comm_status": (C.c_int, [_ptr, C.POINTER(_i32)]),
     "mopoe_comm_destroy": (C.c_int, [_ptr]),
+    "mopoe_rccl_unique_id": (C.c_int, [_ptr]),
+    "mopoe_rccl_create": (C.c_int, [_i32, _i32, _ptr, C.POINTER(_ptr)]),
+    "mopoe_rccl_train_step": (C.c_int, [_ptr, C.POINTER(Model), C.POINTER(Step),
+                                        C.POINTER(Buffers), C.POINTER(Adam), _ptr]),
+    "mopoe_rccl_allreduce": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr]),
+    "mopoe_rccl_destroy": (C.c_int, [_ptr]),
     "mopoe_linear": (C.c_int, [_ptr, _i32, _i32, _ptr, _ptr, _i32, _i32, _ptr,
                                _ptr]),
     "mopoe_poe": (C.c_int, [_ptr, _ptr, _i32, C.c_int64, _f32, _ptr, _ptr,
@@ -242,6 +250,11 @@ def device_rows(t, device=None):
     if t.device == device and t.dtype == torch.float32 and t.is_contiguous():
         return t
     return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def reload_knobs():
+    """Re-read the library's environment knobs (it reads them once, when it is loaded)."""
+    check(lib.mopoe_reload_knobs(), "mopoe_reload_knobs")
 
 
 def profile_enable(on):

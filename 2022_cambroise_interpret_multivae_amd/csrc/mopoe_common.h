@@ -720,6 +720,9 @@ struct XgPeers {
     float inv_world;
     int32_t mask;                        // modalities in this rank's batch (0 when the
                                          // exchange is a plain all-reduce)
+    int32_t fail_slot;                   // (test knob MOPOE_TEST_XG_FAIL_SLOT, else -1) the
+                                         // exchanging block whose wait is reported as failed
+    int32_t pad0;
     size_t p4pad;                        // float4 per (parity, source) inbox
     size_t flags_off, status_off;        // byte offsets inside a window
     void* window[MOPOE_MAX_RANKS];       // base of every rank's window as mapped HERE
@@ -734,6 +737,7 @@ struct XgPeers {
 // Returns true when the exchange is NOT good: a wait ran out of its budget (also counted
 // in the window's status word) or a peer's batch held other modalities.
 DEV bool xg_signal_and_wait(const XgPeers& x, int tid, int slot) {
+    if (slot == x.fail_slot) return tid == 0;   // (test knob: ONE block of the launch fails)
     if (tid >= x.world || tid == x.rank) return false;
     uint32_t* out = reinterpret_cast<uint32_t*>(static_cast<char*>(x.window[tid]) + x.flags_off) +
                     (size_t)x.rank * x.flag_stride + slot;

@@ -1,17 +1,21 @@
 // mopoe_kernels.hip -- hand-written gfx950 kernels of the MoPoE-VAE training
 // step and the C ABI declared in include/mopoe_hip.h.
 //
-// One training step = three launches on the caller's stream:
-//   k_linear       h_m = relu(x_m W1_m^T + b1_m)            (MFMA, grid over
-//                  row tiles x hidden column groups x modalities)
-//   k_latent       per 16-row group, everything that is per-sample: encoder
-//                  heads (MFMA), powerset-of-experts fusion + KL + mixture
-//                  selection + reparameterisation (VALU, wave reductions),
-//                  decoder + Gaussian NLL (MFMA + epilogue) and the whole
-//                  data-gradient chain back to the pre-ReLU gradient
-//   k_wgrad        all weight/bias gradients as reductions over the batch
-//                  (MFMA), with the Adam update fused into the epilogue when
-//                  there is no cross-rank all-reduce in between
+// One training step = TWO launches on the caller's stream while its grid fits the chip
+// (batches of up to a few thousand rows):
+//   k_fused<FORM>  producer workgroups: h_m = relu(x_m W1_m^T + b1_m) (MFMA, per row
+//                  tile x hidden column block x modality), handed over through memory to
+//                  the consumer workgroups of the SAME launch, one per row group (16 rows,
+//                  or 4 in the four-row form of batches <= 256: FORM 4 / 5): everything
+//                  that is per-sample -- encoder heads (MFMA), powerset-of-experts fusion
+//                  + KL + mixture selection + reparameterisation (VALU, wave reductions),
+//                  decoder + NLL (MFMA + epilogue) and the whole data-gradient chain back
+//                  to the pre-ReLU gradient (latent_body, mopoe_latent.inc)
+//   k_wgrad        all weight / bias gradients as reductions over the batch (MFMA), the
+//                  Adam update fused into the epilogue when no exchange sits in between
+// Larger batches (and MOPOE_NO_FUSE=1) keep the first launch in two: k_linear (or
+// k_linear_big), then k_latent = latent_body on its own.  A data-parallel step adds the
+// gradient exchange (RCCL: mopoe_rccl.inc; peer windows: mopoe_xgmi.inc) and k_adam.
 // The math follows SURVEY.md Appendix A; reference file:line citations are in
 // include/mopoe_hip.h and DESIGN.md.
 #include <hip/hip_runtime.h>
@@ -1438,14 +1442,19 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
     if (a.st.backward) {
         const int s = buf.counters[MOPOE_CTR_STEPS_BEGUN];
         const int invalid = buf.counters[MOPOE_CTR_INVALID];
+        // (control word MAX_MODS: this rank's backward was not completed -- adam_step_valid)
+        if (tid == MOPOE_MAX_MODS) buf.grads[a.mdl.off_ctrl + MOPOE_MAX_MODS] = invalid ? 1.f : 0.f;
         // (the GEMM blocks read slot s & 1 and never the counts: nothing they read changes)
         if (fuse) step_end(buf.counters, s, tid, a.mdl.num_mods, a.st.present_mask, invalid == 0, w.adam);
         if (tid == 0) {
             const int done = buf.counters[MOPOE_CTR_STEPS_DONE] + 1;
             buf.counters[MOPOE_CTR_STEPS_DONE] = done;
+            int first = buf.counters[MOPOE_CTR_FIRST_INVALID];
+            if (invalid && first == 0) buf.counters[MOPOE_CTR_FIRST_INVALID] = first = s;
             if (buf.status_host) {
                 buf.status_host[0] = done;
                 buf.status_host[1] = invalid;
+                buf.status_host[2] = first;
             }
         }
     }
@@ -1488,9 +1497,14 @@ struct AdamSegs {
 // buffer is then `world` for a present modality and 0 for an absent one.
 DEV bool adam_step_valid(const mopoe_buffers& buf, const AdamSegs& s, const float* ctrl) {
     bool ok = buf.counters[MOPOE_CTR_INVALID] == 0;
-    if (s.world > 1)
+    if (s.world > 1) {
         for (int m = 0; m < s.num_mods; ++m)
             ok &= ctrl[m] == ((s.present_mask >> m) & 1 ? (float)s.world : 0.f);
+        // control word MAX_MODS: how many ranks could not complete their backward (a hand-off
+        // time-out raises MOPOE_CTR_INVALID on that rank alone): then NO rank applies the step,
+        // every rank raises its sticky word below, and all of them notice together
+        ok &= ctrl[MOPOE_MAX_MODS] == 0.f;
+    }
     return ok;
 }
 // The block that finishes last ends the step: counts, next step's records, the sticky
@@ -1510,7 +1524,11 @@ DEV void adam_kernel_end(const mopoe_buffers& buf, const AdamSegs& s, bool valid
     if (tid == 0) {
         buf.counters[MOPOE_CTR_TICKET] = 0;
         if (!valid && buf.counters[MOPOE_CTR_INVALID] == 0) buf.counters[MOPOE_CTR_INVALID] = 1;
-        if (buf.status_host) buf.status_host[1] = buf.counters[MOPOE_CTR_INVALID];
+        if (!valid && buf.counters[MOPOE_CTR_FIRST_INVALID] == 0) buf.counters[MOPOE_CTR_FIRST_INVALID] = step;
+        if (buf.status_host) {
+            buf.status_host[1] = buf.counters[MOPOE_CTR_INVALID];
+            buf.status_host[2] = buf.counters[MOPOE_CTR_FIRST_INVALID];
+        }
     }
 }
 
@@ -1829,18 +1847,51 @@ void bind_buffers(KArgs& ka, const mopoe_buffers& buf) {
 // groups on four times the CUs, each issuing a quarter of the MFMAs.
 // One decoder pass (FORM 4), or two whose jobs are the same modalities in the same order
 // (FORM 5: method poe's joint + unimodal jobs).  MOPOE_QUAD=0 turns it off.
-int quad_max_rows() {   // (MOPOE_QUAD_MAX_N: experiments)
-    const char* v = getenv("MOPOE_QUAD_MAX_N");
-    return v ? atoi(v) : 256;
+// The environment knobs (tests, experiments), read ONCE: a training step makes no getenv
+// call -- a linear scan of the environment each -- and a setenv in mid-run cannot switch
+// kernels between two steps of one run.  mopoe_reload_knobs() re-reads them (the tests that
+// compare launch forms inside one process call it after changing the environment).
+struct Knobs {
+    int quad_max_n;      // MOPOE_QUAD_MAX_N: rows up to which the four-row form is used (256)
+    bool quad;           // MOPOE_QUAD=0 turns the four-row form off
+    bool no_fuse;        // MOPOE_NO_FUSE: encoder layer and per-sample chain in two launches
+    bool no_lean;        // MOPOE_NO_LEAN: the generic instantiation of the fused launch
+    int q1_idle;         // MOPOE_Q1_IDLE: waves the four-row heads stage leaves free (2)
+    int handoff_spins;   // MOPOE_TEST_HANDOFF_SPINS: polls of a row group before it gives up
+    int fuse_blocks;     // MOPOE_FUSE_BLOCKS: largest grid the fused launch is used for (256)
+    int knock;           // MOPOE_KNOCK (diagnostic build): phases to leave out
+    bool wgrad_nofold, wgrad_tall;   // MOPOE_WGRAD_NOFOLD / MOPOE_WGRAD_TALL: experiments
+    int xg_fail_slot;    // MOPOE_TEST_XG_FAIL_SLOT: the exchanging block that reports a failed wait (-1)
+};
+Knobs read_knobs() {
+    auto num = [](const char* name, int dflt) {
+        const char* v = getenv(name);
+        return v ? (int)strtol(v, nullptr, 0) : dflt;
+    };
+    Knobs k;
+    k.quad_max_n = num("MOPOE_QUAD_MAX_N", 256);
+    k.quad = num("MOPOE_QUAD", 1) != 0;
+    k.no_fuse = getenv("MOPOE_NO_FUSE") != nullptr;
+    k.no_lean = getenv("MOPOE_NO_LEAN") != nullptr;
+    k.q1_idle = num("MOPOE_Q1_IDLE", 2);
+    k.handoff_spins = num("MOPOE_TEST_HANDOFF_SPINS", kHandoffSpins);
+    k.fuse_blocks = num("MOPOE_FUSE_BLOCKS", 256);
+    k.knock = num("MOPOE_KNOCK", 0);
+    k.wgrad_nofold = getenv("MOPOE_WGRAD_NOFOLD") != nullptr;
+    k.wgrad_tall = getenv("MOPOE_WGRAD_TALL") != nullptr;
+    k.xg_fail_slot = num("MOPOE_TEST_XG_FAIL_SLOT", -1);
+    return k;
 }
+Knobs g_knobs = read_knobs();
+
+int quad_max_rows() { return g_knobs.quad_max_n; }
 int quad_first_pass_jobs(const mopoe_step& st) {   // jobs of the first decoder pass (slot)
     int n0 = 0;
     while (n0 < st.num_jobs && st.job_slot[n0] == st.job_slot[0]) ++n0;
     return n0;
 }
 bool quad_step(const mopoe_model& mdl, const mopoe_step& st) {
-    const char* v = getenv("MOPOE_QUAD");
-    if (v && atoi(v) == 0) return false;
+    if (!g_knobs.quad) return false;
     if (!st.backward || !st.sample || st.joint_mode != MOPOE_JOINT_MIXTURE || st.group_rows != 0 ||
         st.rows_per_group != 0 || mdl.num_mods > 2 || st.num_jobs > 4 || st.n > quad_max_rows() || st.n < 4 ||
         st.likelihood != MOPOE_LIK_NORMAL)
@@ -1858,7 +1909,7 @@ bool quad_step(const mopoe_model& mdl, const mopoe_step& st) {
                 return false;
         }
     }
-    return getenv("MOPOE_NO_FUSE") == nullptr && getenv("MOPOE_NO_LEAN") == nullptr;
+    return !g_knobs.no_fuse && !g_knobs.no_lean;
 }
 // THE layout of a step: every caller (launches, mopoe_row_groups, mopoe_latent_lds_bytes)
 // goes through here, so they agree on the rows per group
@@ -1902,8 +1953,7 @@ bool quad_tables(const mopoe_model& mdl, const mopoe_step& st, LatentLds& L) {
     {   // at least two waves of the heads stage stay free: they draw the step's noise meanwhile
         // (measured, configs[1]: 5 K parts and one free wave +0.27 us, 4 parts and four -0.3 us
         //  against the noise drawn in S0; MOPOE_Q1_IDLE: experiments)
-        const char* v = getenv("MOPOE_Q1_IDLE");
-        const int idle = v ? atoi(v) : 2;
+        const int idle = g_knobs.q1_idle;
         L.q1_parts = (kLatentWaves - idle) / tiles1;
         if (L.q1_parts < 1) L.q1_parts = kLatentWaves / tiles1;
     }
@@ -2016,20 +2066,14 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s, 
 }
 
 // MOPOE_NO_FUSE=1 keeps the encoder layer and the per-sample chain in two launches;
-// MOPOE_FUSE_BLOCKS caps the grid the fused launch is used for.  Read per call (two
-// getenv), so a test can compare the two forms inside one process.
-static bool no_fuse() { return getenv("MOPOE_NO_FUSE") != nullptr; }
+// MOPOE_FUSE_BLOCKS caps the grid the fused launch is used for (Knobs: read once; a test
+// that compares the two forms inside one process calls mopoe_reload_knobs in between).
+static bool no_fuse() { return g_knobs.no_fuse; }
 // MOPOE_TEST_HANDOFF_SPINS: a test knob -- with 0 every row group of the fused launch gives
 // up without looking at its flag, which is how tests/test_hip_invalid.py drives the "step
 // could not be completed" path (flags left non-zero by the producers included).
-static int handoff_spins() {
-    const char* v = getenv("MOPOE_TEST_HANDOFF_SPINS");
-    return v ? atoi(v) : kHandoffSpins;
-}
-static int fuse_blocks() {
-    const char* v = getenv("MOPOE_FUSE_BLOCKS");
-    return v ? atoi(v) : 256;
-}
+static int handoff_spins() { return g_knobs.handoff_spins; }
+static int fuse_blocks() { return g_knobs.fuse_blocks; }
 
 // Which instantiation of the fused launch serves this step (latent_body's FORM); 0 = the
 // generic one.  MOPOE_NO_LEAN=1 forces the generic form (the forms are bit-identical:
@@ -2038,7 +2082,7 @@ int launch_form(const KArgs& ka) {
     const mopoe_model& mdl = ka.mdl;
     const mopoe_step& st = ka.st;
     const LatentLds& L = ka.lds;
-    if (getenv("MOPOE_NO_LEAN") != nullptr) return 0;
+    if (g_knobs.no_lean) return 0;
     if (!st.backward || !st.sample || st.joint_mode != MOPOE_JOINT_MIXTURE || st.group_rows != 0 ||
         L.rows != kRows || st.likelihood != MOPOE_LIK_NORMAL)
         return 0;   // (four-row groups: the caller picks form 4)
@@ -2060,7 +2104,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     la.num_mods = mdl.num_mods;
     la.spins = handoff_spins();
 #ifdef MOPOE_KNOCK
-    la.knock = getenv("MOPOE_KNOCK") ? (int)strtol(getenv("MOPOE_KNOCK"), nullptr, 0) : 0;
+    la.knock = g_knobs.knock;
 #endif
     if (adam) la.adam = *adam;
     int maxd = 1;
@@ -2221,10 +2265,10 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w, const XgPeer
             // + the bias column, unless the rows are a whole number of tiles (WJob::fold)
             // (small batches only: there the count of blocks decides; with tens of thousands of
             //  rows every block is MFMA-bound and the extra adds make the folded ones the last)
-            jb.fold = jb.xcols % 32 == 0 && st.n <= 2048 && !getenv("MOPOE_WGRAD_NOFOLD");
+            jb.fold = jb.xcols % 32 == 0 && st.n <= 2048 && !g_knobs.wgrad_nofold;
             jb.tiles_j = cdiv(jb.xcols + (jb.fold ? 0 : 1), 32);
             // (a job over at least twice the step's batch rows: 16-row tiles, see WJob::th)
-            jb.th = (k == 2 && jb.R >= 2 * st.n && !getenv("MOPOE_WGRAD_TALL")) ? 16 : 32;
+            jb.th = (k == 2 && jb.R >= 2 * st.n && !g_knobs.wgrad_tall) ? 16 : 32;
             jb.tile_begin = tile;
             w.tile_begin[w.njobs] = tile;
             tile += cdiv(jb.gcols, jb.th) * jb.tiles_j;
@@ -2283,9 +2327,31 @@ int build_adam_segs(const mopoe_model& mdl, int32_t present_mask, const mopoe_ad
 void comm_next(mopoe_comm* c, XgPeers& x);
 int comm_flag_stride(const mopoe_comm* c);
 int comm_check(const mopoe_comm* c, const mopoe_model* mdl);
+int comm_world(const mopoe_comm* c);
 
+// k_adam on the flat buffers with the gradient scaled by 1 / world.  `ctrl_check`: the
+// gradient buffer went through an all-reduce that also summed its control words (the ranks'
+// modality masks and invalid flags: adam_step_valid); false when the exchange compared the
+// masks itself (the xGMI forms: the masks travel in the arrival flags).
+int launch_adam(const mopoe_model& mdl, int32_t present_mask, const mopoe_buffers& buf,
+                const mopoe_adam& adam, int32_t world, bool ctrl_check, hipStream_t s) {
+    if (!buf.params || !buf.grads || !buf.exp_avg || !buf.exp_avg_sq || !buf.counters)
+        return fail(MOPOE_ERR_ARG, "null optimiser buffer%s");
+    AdamSegs sg;
+    if (int rc = build_adam_segs(mdl, present_mask, adam, world, sg)) return rc;
+    if (!ctrl_check) sg.world = 1;   // (grad_scale stays 1 / world)
+    {
+        ProfScope ps(MOPOE_KERNEL_ADAM, s);
+        hipLaunchKernelGGL(k_adam, dim3(64, sg.nseg), dim3(256), 0, s, buf, sg);
+    }
+    return check_launch("k_adam");   // (the fragment-major weight copies included)
+}
+
+// `fuse_adam`: the weight-gradient launch applies the update itself (the one-rank step).
+// Otherwise the launches stop at the gradients -- with `adam` non-NULL the step's first
+// kernel still publishes its Adam records for the k_adam launch that follows an exchange.
 int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* buf,
-                    const mopoe_adam* adam, mopoe_comm* comm, void* stream) {
+                    const mopoe_adam* adam, mopoe_comm* comm, bool fuse_adam, void* stream) {
     if (int rc = validate(mdl, st, buf, true)) return rc;
     if (adam && (!buf->exp_avg || !buf->exp_avg_sq))
         return fail(MOPOE_ERR_ARG, "null Adam state%s");
@@ -2303,7 +2369,10 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
     latent_bind(ka.lds, ka.buf);
     hipStream_t s = static_cast<hipStream_t>(stream);
     WArgs w;
-    build_wargs(ka, adam, w);
+    // (the exchanging launch does not apply the update itself: whether every block's exchange
+    //  was good is known at the END of the launch, and a step is applied whole or not at all
+    //  -- k_adam behind it decides for the whole step)
+    build_wargs(ka, (comm || !fuse_adam) ? nullptr : adam, w);
     const dim3 grid(w.total_tiles + w.lvo_blocks + 1);
     // (checked before anything is launched: a refused call leaves no half step behind and
     //  does not advance the exchange's sequence number)
@@ -2331,7 +2400,9 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
                 hipLaunchKernelGGL((k_wgrad<4, false>), grid, dim3(256), 0, s, ka, w);
         }
     }
-    return check_launch("k_wgrad");
+    if (int rc = check_launch("k_wgrad")) return rc;
+    if (comm) return launch_adam(*mdl, ka.st.present_mask, *buf, *adam, comm_world(comm), false, s);
+    return 0;
 }
 
 int launch_wfrag(const mopoe_model& mdl, const mopoe_buffers& buf, hipStream_t s) {
@@ -2348,6 +2419,11 @@ int launch_wfrag(const mopoe_model& mdl, const mopoe_buffers& buf, hipStream_t s
 extern "C" {
 
 int mopoe_abi_version(void) { return MOPOE_ABI_VERSION; }
+
+int mopoe_reload_knobs(void) {
+    g_knobs = read_knobs();
+    return 0;
+}
 
 const char* mopoe_last_error(void) { return g_err; }
 
@@ -2456,22 +2532,13 @@ int mopoe_forward(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buff
 
 int mopoe_train_step(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* buf,
                      const mopoe_adam* adam, void* stream) {
-    return train_step_impl(mdl, st, buf, adam, nullptr, stream);
+    return train_step_impl(mdl, st, buf, adam, nullptr, true, stream);
 }
 
 int mopoe_adam_step(const mopoe_model* mdl, int32_t present_mask, const mopoe_buffers* buf,
                     const mopoe_adam* adam, int32_t world, void* stream) {
     if (!mdl || !buf || !adam) return fail(MOPOE_ERR_ARG, "null descriptor%s");
-    if (!buf->params || !buf->grads || !buf->exp_avg || !buf->exp_avg_sq || !buf->counters)
-        return fail(MOPOE_ERR_ARG, "null optimiser buffer%s");
-    AdamSegs sg;
-    if (int rc = build_adam_segs(*mdl, present_mask, *adam, world, sg)) return rc;
-    {
-        ProfScope ps(MOPOE_KERNEL_ADAM, static_cast<hipStream_t>(stream));
-        hipLaunchKernelGGL(k_adam, dim3(64, sg.nseg), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), *buf, sg);
-    }
-    return check_launch("k_adam");   // (the fragment-major weight copies included)
+    return launch_adam(*mdl, present_mask, *buf, *adam, world, true, static_cast<hipStream_t>(stream));
 }
 
 int mopoe_wfrag_refresh(const mopoe_model* mdl, const mopoe_buffers* buf, void* stream) {
@@ -2616,7 +2683,7 @@ int mopoe_comm_connect(mopoe_comm* c, const void* handles) {
 
 int mopoe_comm_allreduce(mopoe_comm* c, float* data, void* stream) {
     if (!c || !data) return fail(MOPOE_ERR_ARG, "mopoe_comm_allreduce: null argument%s");
-    return comm_launch(c, data, nullptr, nullptr, static_cast<hipStream_t>(stream));
+    return comm_launch(c, data, nullptr, 0, static_cast<hipStream_t>(stream));
 }
 
 int mopoe_comm_allreduce_adam(mopoe_comm* c, const mopoe_model* mdl, int32_t present_mask,
@@ -2626,16 +2693,17 @@ int mopoe_comm_allreduce_adam(mopoe_comm* c, const mopoe_model* mdl, int32_t pre
         return fail(MOPOE_ERR_ARG, "null optimiser buffer%s");
     if (mdl->num_floats != c->num_floats)
         return fail(MOPOE_ERR_ARG, "communicator was created for another buffer length%s");
-    AdamSegs sg;
-    if (int rc = build_adam_segs(*mdl, present_mask, *adam, c->world, sg)) return rc;
-    if (int rc = comm_launch(c, buf->grads, buf, &sg, static_cast<hipStream_t>(stream))) return rc;
-    return buf->wfrag ? launch_wfrag(*mdl, *buf, static_cast<hipStream_t>(stream)) : 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (present_mask <= 0 || present_mask >= (1 << mdl->num_mods))
+        return fail(MOPOE_ERR_ARG, "present_mask out of range%s");   // (before the exchange is launched)
+    if (int rc = comm_launch(c, buf->grads, buf->counters, present_mask, s)) return rc;
+    return launch_adam(*mdl, present_mask, *buf, *adam, c->world, false, s);
 }
 
 int mopoe_comm_train_step(mopoe_comm* c, const mopoe_model* mdl, const mopoe_step* st,
                           const mopoe_buffers* buf, const mopoe_adam* adam, void* stream) {
     if (!c) return fail(MOPOE_ERR_ARG, "mopoe_comm_train_step: null communicator%s");
-    return train_step_impl(mdl, st, buf, adam, c, stream);
+    return train_step_impl(mdl, st, buf, adam, c, false, stream);
 }
 
 int mopoe_comm_status(mopoe_comm* c, int32_t* timeouts) {
@@ -2656,3 +2724,5 @@ int mopoe_comm_destroy(mopoe_comm* c) {
 }
 
 }  // extern "C"
+
+#include "mopoe_rccl.inc"

@@ -80,6 +80,7 @@ class MoPoEEngine:
         self.grad_views = spec.param_views(self.grads)
         self.seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1)
         self._calls = 0
+        self._train_calls = 0    # training steps enqueued (run_epochs._FusedLoss)
         self._ws = {}
         self._keep = None   # tensors the in-flight kernels read (x, eps)
         self.adam = L.Adam(spec.lr, spec.betas[0], spec.betas[1], spec.adam_eps)
@@ -138,13 +139,25 @@ class MoPoEEngine:
                 "update has been applied since -- engine.recover() re-arms the step"
                 % bad)
 
+    def invalid_since(self):
+        """(first step that was not applied, steps begun) after a synchronisation, or None
+        when every step so far was applied.  The steps first .. begun were withheld (the
+        invalid word is sticky): after `recover()` the caller runs those batches again."""
+        torch.cuda.synchronize(self.device)
+        c = self.counters[:4].tolist()
+        if not c[L.CTR_INVALID]:
+            return None
+        return c[L.CTR_FIRST_INVALID], c[L.CTR_STEPS_BEGUN]
+
     def recover(self):
         """Re-arm after an invalid step: clears the sticky word and the hand-off flags."""
         torch.cuda.synchronize(self.device)
         self.counters[L.CTR_INVALID] = 0
+        self.counters[L.CTR_FIRST_INVALID] = 0
         for ws in self._ws.values():
             ws.partials.zero_()
         self.status_host[1] = 0
+        self.status_host[2] = 0
         torch.cuda.synchronize(self.device)
 
     # --------------------------------------------------------------- buffers
@@ -311,15 +324,19 @@ class MoPoEEngine:
         return plan, ws
 
     def train_step(self, batch, eps=None, row_index=None, apply_adam=True,
-                   stats_host=None, comm=None, loss_scale=1.0):
+                   stats_host=None, comm=None, loss_scale=1.0, rccl=None, check=True):
         """mopoe_train_step: forward + backward (+ fused Adam).  `stats_host`:
         a pinned host tensor the kernel writes the step's scalars into (the
         per-step log without a copy on the stream; read it after a sync or a
         few steps later).  `comm` (an XgmiComm): mopoe_comm_train_step -- the
         weight-gradient launch exchanges its blocks with the other ranks and
         applies Adam with the mean (all ranks: same modalities in the batch).
-        `loss_scale`: weight of the batch's loss terms (parallel.py)."""
-        self.check_valid()          # (pinned host mirror: no synchronisation)
+        `rccl` (an RcclComm): mopoe_rccl_train_step -- backward, RCCL all-reduce of the
+        gradient buffer and Adam with the mean, enqueued by this one call.
+        `loss_scale`: weight of the batch's loss terms (parallel.py).
+        `check=False`: the caller looks after invalid steps itself (parallel.StepRetry)."""
+        if check:
+            self.check_valid()      # (pinned host mirror: no synchronisation)
         x, n, row_index = self._prepare(batch, row_index)
         plan = self.spec.plan(list(x.keys()), n, True, None, True, True,
                               loss_scale=loss_scale)
@@ -330,16 +347,22 @@ class MoPoEEngine:
         step.seed = self.seed
         buf = self._buffers(ws, x, row_index, stats_host, plan=plan)
         adam = C.byref(self.adam) if apply_adam else None
-        if comm is not None:
-            if not apply_adam:
-                raise ValueError("the exchanging step applies Adam")
-            L.check(L.lib.mopoe_comm_train_step(comm._c, self.spec.c_model, step, buf,
-                                                adam, L.stream_ptr()),
-                    "mopoe_comm_train_step")
+        if comm is not None or rccl is not None:
+            if not apply_adam or (comm is not None and rccl is not None):
+                raise ValueError("the exchanging step applies Adam (through ONE communicator)")
+            if rccl is not None:
+                L.check(L.lib.mopoe_rccl_train_step(rccl._c, self.spec.c_model, step, buf,
+                                                    adam, L.stream_ptr()),
+                        "mopoe_rccl_train_step")
+            else:
+                L.check(L.lib.mopoe_comm_train_step(comm._c, self.spec.c_model, step, buf,
+                                                    adam, L.stream_ptr()),
+                        "mopoe_comm_train_step")
         else:
             L.check(L.lib.mopoe_train_step(self.spec.c_model, step, buf, adam,
                                            L.stream_ptr()), "mopoe_train_step")
         self._keep = (x, keep, row_index)
+        self._train_calls += 1
         self.last_present_mask = step.present_mask
         return plan, ws
 

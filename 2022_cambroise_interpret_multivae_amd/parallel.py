@@ -1,6 +1,6 @@
 """Data-parallel replicas: one process per GPU, identical models, one exchange of the
-flat float32 gradient buffer per step (torch.distributed: backend "nccl" = RCCL over
-xGMI on the GPU node, "gloo" in the CPU tests).
+flat float32 gradient buffer per step (RCCL over xGMI on the GPU node; torch.distributed
+"gloo" in the CPU tests).
 
 The reference has no distributed code; the contract here is
 section 8e.  A step of W ranks on per-rank batches of n_r rows is ONE step of the
@@ -17,13 +17,23 @@ reference on the global batch of sum(n_r) rows:
     last batch of a modality subset;
   * the mixture slices of mixture_component_selection (utils/utils.py:63-85) are
     applied per rank (row position inside the rank's batch): equal to the single
-    process only in expectation when the mixture has more than one component.
+    process only in expectation when the mixture has more than one component;
+  * a step that ONE rank could not complete (a hand-off time-out in its fused launch) is
+    applied by NO rank: the rank's invalid flag is another control word of the summed
+    buffer, every rank raises its sticky invalid word at the same step, and StepRetry
+    re-arms all of them and runs the same batches again.
 
-The exchange is RCCL's all-reduce by default.  The peer-window exchange of comm.py
-(xGMI, rank-ordered sums) is opt-in: it has only ever run between processes that share
-one GPU."""
+The exchange is RCCL's all-reduce, by default bound inside the C ABI
+(comm.RcclComm: backward, all-reduce and Adam are ONE host call per step); "allreduce"
+spells the same step out over torch.distributed (any backend: the CPU tests).  The
+peer-window exchange of comm.XgmiComm is opt-in: it has only ever run between processes
+that share one GPU."""
+import collections
+
 import torch
 import torch.distributed as dist
+
+from . import _lib as L
 
 
 def world_size():
@@ -62,36 +72,73 @@ def share_schedule(batches, src=0):
 class DataParallelStep:
     """engine.train_step + gradient exchange + Adam with the mean, as one call.
 
-    exchange = "allreduce" (default): torch.distributed all_reduce of engine.grads
-        (RCCL over xGMI on the node) + mopoe_adam_step(world).
-    exchange = "xgmi": `comm` (an XgmiComm) pushes the buffer to every peer's window,
-        sums in rank order and applies Adam in ONE launch after the backward;
+    exchange = "rccl" (default on the GPU under the nccl backend): mopoe_rccl_train_step
+        -- backward, ncclAllReduce of engine.grads and the Adam launch enqueued by ONE
+        call of the C ABI over the library's own communicator (comm.RcclComm);
+    exchange = "allreduce" (default otherwise): the same step spelled out --
+        engine.train_step, torch.distributed all_reduce, engine.adam_step(world);
+    exchange = "xgmi": `comm` (an XgmiComm) pushes the buffer to every peer's window and
+        sums in rank order in one launch after the backward, then the Adam launch;
     exchange = "xgmi_in_backward": the weight-gradient launch itself exchanges every
-        gradient block (the N-rank step has the two launches of the 1-rank step).
+        gradient block, then the Adam launch.
     Every form refuses the update when the ranks' batches held different modalities."""
 
-    FORMS = ("allreduce", "xgmi", "xgmi_in_backward")
+    FORMS = ("rccl", "allreduce", "xgmi", "xgmi_in_backward")
 
     def __init__(self, engine, comm=None, exchange=None):
         if exchange is None:
-            exchange = "allreduce" if comm is None else "xgmi"
+            if comm is not None:
+                exchange = "xgmi"
+            elif (world_size() > 1 and getattr(engine, "_on_gpu", False)
+                  and dist.get_backend() == "nccl"):
+                exchange = "rccl"
+            else:
+                exchange = "allreduce"
         if exchange not in self.FORMS:
             raise ValueError("exchange must be one of %s" % (self.FORMS,))
-        if exchange != "allreduce" and comm is None:
+        if exchange.startswith("xgmi") and comm is None:
             raise ValueError("exchange %r needs an XgmiComm" % exchange)
         self.engine = engine
         self.comm = comm
         self.exchange = exchange
-        broadcast_parameters(engine.params)
-        broadcast_parameters(engine.exp_avg)
-        broadcast_parameters(engine.exp_avg_sq)
-        broadcast_parameters(engine.counters)     # step numbers, Adam counts
+        self.rccl = None
+        if exchange == "rccl":
+            from .comm import RcclComm
+            self.rccl = comm if isinstance(comm, RcclComm) else RcclComm()
+        self.synchronise_replicas()
 
-    def __call__(self, batch, eps=None, row_index=None, loss_scale=1.0, stats_host=None):
+    def synchronise_replicas(self, src=0):
+        """Rank `src`'s parameters, moments and step counts on every rank.  c10d
+        collectives do not bump tensor._version: the fragment-major weight copies the
+        four-row form reads are rebuilt explicitly."""
+        eng = self.engine
+        broadcast_parameters(eng.params, src)
+        broadcast_parameters(eng.exp_avg, src)
+        broadcast_parameters(eng.exp_avg_sq, src)
+        broadcast_parameters(eng.counters, src)     # step numbers, Adam counts
+        if getattr(eng, "_on_gpu", False):
+            eng.refresh_wfrag()
+
+    def recover(self):
+        """Re-arm every rank after an invalid step.  The RCCL / all-reduce forms withhold
+        the step on every rank together (control words), so re-arming is enough.  A
+        time-out of a peer-window form is seen by the rank that waited only: every rank
+        holds a whole step, but the ranks may be one step apart -- rank 0's state is
+        broadcast again."""
+        self.engine.recover()
+        if self.exchange.startswith("xgmi"):
+            self.synchronise_replicas()
+
+    def __call__(self, batch, eps=None, row_index=None, loss_scale=1.0, stats_host=None,
+                 check=True):
         eng = self.engine
         kw = dict(eps=eps, row_index=row_index, loss_scale=loss_scale, stats_host=stats_host)
-        if world_size() == 1:
+        if hasattr(eng, "invalid_since"):
+            kw["check"] = check
+        if world_size() == 1 and self.rccl is None:
             return eng.train_step(batch, apply_adam=True, **kw)
+        if self.exchange == "rccl":
+            return eng.train_step(batch, apply_adam=True, rccl=self.rccl, **kw)
         if self.exchange == "xgmi_in_backward":
             return eng.train_step(batch, apply_adam=True, comm=self.comm, **kw)
         out = eng.train_step(batch, apply_adam=False, **kw)
@@ -99,4 +146,74 @@ class DataParallelStep:
             self.comm.allreduce_adam(eng)
         else:
             eng.adam_step(world=allreduce_sum_(eng.grads))
+        return out
+
+
+class StepRetry:
+    """The loop's policy for a step that could not be completed (reference
+    run_epochs.py:180-182 applies a step or nothing): the kernels withhold the update from
+    the first invalid step on (sticky word, on every rank at the same step); this notices,
+    re-arms and runs the withheld batches ONCE more, and raises if that fails too.
+
+    `run(*args, **kw)` enqueues one training step.  One process: the pinned host mirror
+    the kernels write is read after every step (no synchronisation).  Data-parallel
+    replicas must decide at the same step, so they look synchronously every `depth // 2`
+    steps and at `flush()` (the end of an epoch); `depth` batches are kept for the replay.
+    A replayed step draws fresh noise (the device generator is keyed by the step number)
+    and is logged again by the caller."""
+
+    def __init__(self, engine, run, recover=None, depth=64, world=None):
+        self.engine = engine
+        self.run = run
+        self.recover = recover if recover is not None else engine.recover
+        self.depth = int(depth)
+        self.world = world_size() if world is None else world
+        self.history = collections.deque(maxlen=self.depth)
+        self.retries = 0
+        self._since = 0
+
+    def step(self, *args, **kw):
+        out = self.run(*args, **kw)
+        self.history.append((args, kw))
+        self._since += 1
+        if self.world == 1:
+            bad = int(self.engine.status_host[1]) != 0
+        else:
+            bad = self._since >= max(1, self.depth // 2) and self._look()
+        if bad:
+            out = self._redo() or out
+        return out
+
+    def flush(self):
+        """End of an epoch: nothing invalid is left behind (synchronises)."""
+        if self._look():
+            self._redo()
+        self.history.clear()
+
+    def _look(self):
+        self._since = 0
+        return self.engine.invalid_since() is not None
+
+    def _redo(self):
+        info = self.engine.invalid_since()
+        if info is None:
+            return None
+        first, begun = info
+        k = begun - first + 1
+        if first <= 0 or k > len(self.history):
+            raise L.MopoeError(
+                "training steps %d..%d could not be completed and only the last %d batches "
+                "are kept for a retry" % (first, begun, len(self.history)))
+        replay = list(self.history)[-k:]
+        self.recover()
+        self.retries += 1
+        out = None
+        for args, kw in replay:
+            out = self.run(*args, **kw)
+        if self.engine.invalid_since() is not None:
+            raise L.MopoeError(
+                "%d training step(s) could not be completed twice in a row (hand-off or "
+                "gradient-exchange time-out, or ranks with different modalities); the "
+                "parameters are those of the last complete step" % k)
+        self._since = 0
         return out

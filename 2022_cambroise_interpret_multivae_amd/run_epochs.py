@@ -22,15 +22,26 @@ class _FusedLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, loss_view):
         ctx.model = model
+        ctx.step = model.engine._train_calls
         return loss_view.detach().clone()
 
     @staticmethod
     def backward(ctx, grad_out):
         model = ctx.model
         eng = model.engine
-        # the gradients already sit in engine.grads for d(total_loss) = 1; a caller that
-        # scales the loss before .backward() gets them scaled (one in-place multiply)
-        eng.grads.mul_(grad_out)
+        # The gradients already sit in engine.grads for d(total_loss) = 1: they were
+        # computed by the step itself, not by this call.  A second backward() of the same
+        # loss (retain_graph) or one after a later step would scale / publish a buffer that
+        # no longer belongs to this loss: refused.
+        if ctx.step is None or ctx.step != eng._train_calls:
+            raise RuntimeError("total_loss.backward() publishes the gradients of the step "
+                               "that produced it, once: call it before the next training "
+                               "step and not a second time")
+        ctx.step = None
+        # a caller that scales the loss before .backward() gets the gradients scaled: one
+        # in-place multiply over the parameters' part of the buffer (the control words
+        # behind it are left alone)
+        eng.grads[:eng.spec.c_model.off_ctrl].mul_(grad_out)
         mask = eng.last_present_mask
         names = eng.spec.names
         for name, p in model.named_parameters():
@@ -152,14 +163,19 @@ def train(model_idx, epoch, exp, tb_logger):
     world = parallel.world_size()
     if hasattr(dataset, "epoch_schedule"):             # ResidentCohort
         step = _dp_step(exp, model_idx, eng) if world > 1 else None
+        guard = _retry_guard(exp, model_idx, eng, step)
         for inputs, row_index, weight in dataset.epoch_schedule(
                 exp.flags.batch_size, world, parallel.rank()):
             optimizer._sync()
-            if step is None:
+            if guard is not None:
+                plan, ws = guard.step(inputs, row_index, weight)
+            elif step is None:
                 plan, ws = eng.train_step(inputs, row_index=row_index, apply_adam=True)
             else:
                 plan, ws = step(inputs, row_index=row_index, loss_scale=weight)
             _log_step(tb_logger, eng, plan, ws)
+        if guard is not None:
+            guard.flush()               # (a step that could not be completed is run again)
         eng.check_valid(sync=True)      # no half-applied step leaves the epoch unnoticed
         return
     if world > 1:
@@ -176,6 +192,26 @@ def train(model_idx, epoch, exp, tb_logger):
                                           basic_routine["total_loss"],
                                           basic_routine["log_probs"], basic_routine["klds"])
     eng.check_valid(sync=True)
+
+
+def _retry_guard(exp, model_idx, eng, dp_step):
+    """The model's parallel.StepRetry: a training step the kernels could not complete (a
+    transient co-tenant of the GPU can starve a hand-off inside the fused launch) costs one
+    retried step instead of the epoch.  The reference applies a step or nothing
+    (run_epochs.py:180-182); so does this."""
+    if not hasattr(eng, "invalid_since"):
+        return None          # (a stand-in engine without the device-side step protocol)
+    guards = exp.__dict__.setdefault("_retry_guards", {})
+    if model_idx not in guards:
+        if dp_step is None:
+            def run(inputs, row_index, weight):
+                return eng.train_step(inputs, row_index=row_index, apply_adam=True, check=False)
+            guards[model_idx] = parallel.StepRetry(eng, run)
+        else:
+            def run(inputs, row_index, weight):
+                return dp_step(inputs, row_index=row_index, loss_scale=weight, check=False)
+            guards[model_idx] = parallel.StepRetry(eng, run, recover=dp_step.recover)
+    return guards[model_idx]
 
 
 def _dp_step(exp, model_idx, eng):

@@ -18,9 +18,13 @@ again after --settle (3000) untimed steps, which is `value`: what training runs 
 For N > 1 the driver launches one rank per GPU with torch.distributed.run; ranks are
 data-parallel replicas (weak scaling: 256 samples per GPU per step) that exchange the
 flat gradient buffer once per step with RCCL's all-reduce (+ the Adam kernel, which
-also checks that every rank's batch held the same modalities).  MOPOE_EXCHANGE=xgmi
-opts into the peer-window exchange of csrc/mopoe_xgmi.inc (start-up checked against the
-gathered inputs on the node it runs on; it has never run on more than one GPU).
+also checks that every rank's batch held the same modalities and that every rank
+completed its backward) -- ONE host call per step: mopoe_rccl_train_step enqueues the
+backward, ncclAllReduce and the Adam launch over the library's own RCCL communicator.
+MOPOE_EXCHANGE=c10d spells the same step out (train_step, torch.distributed.all_reduce,
+adam_step: three host calls); MOPOE_EXCHANGE=xgmi opts into the peer-window exchange of
+csrc/mopoe_xgmi.inc (start-up checked against the gathered inputs on the node it runs on;
+it has never run on more than one GPU).
 
 Prints ONE JSON line (rank 0).  Besides the contract's keys:
   roofline       the kernel with the largest share of device time, its duration measured
@@ -121,7 +125,9 @@ def kernel_models(spec, n, fused_adam, world=1):
                           bytes=out["k_linear"]["bytes"] + out["k_latent"]["bytes"])
     out["k_adam"] = dict(flops=0.0, bytes=f * 7 * P)
     # push to W-1 peers, read W-1 inboxes, sum written back, Adam read-modify-write
-    out["k_xgmi"] = dict(flops=0.0, bytes=f * P * (8 + 2 * (world - 1)))
+    out["k_xgmi"] = dict(flops=0.0, bytes=f * P * (2 + 2 * (world - 1)))
+    # ring all-reduce: every rank sends and receives 2 (W-1)/W of the buffer
+    out["rccl_allreduce"] = dict(flops=0.0, bytes=f * P * 2.0 * 2.0 * (world - 1) / max(world, 1))
     out["k_finalize"] = dict(flops=0.0, bytes=0.0)
     return out
 
@@ -280,11 +286,11 @@ def oracle_setup(c):
 
 def cpu_baseline(seconds=18.0):
     """The oracle's train step (forward, loss, autograd backward, Adam) on the host cores:
-    a bounded sample of configs[1]'s workload at 1 thread, at the 16 threads that are a
-    one-GPU job's share of the box, and at ALL host cores (SURVEY.md section 8d asks for
-    all and 1).  These ~2,600 tiny ops per step do not scale with threads -- on a
-    256-thread host the all-cores setting takes seconds per step, so that leg is cut off
-    after two steps; the best setting is `value`."""
+    a bounded sample of configs[1]'s workload at 1 thread and at the 16 threads that are a
+    one-GPU job's share of the box (or all of them on a smaller host).  There is no
+    all-cores leg: the step is ~2,600 tiny torch ops that do not scale with threads, and on
+    the 256-thread GPU host the all-cores setting took 16.3 s for ONE step (BENCH_r02.json:
+    oversubscription, not a baseline).  The best setting is `value`, `cores` its threads."""
     c = CONFIGS["C1"]
     mo, cfg = oracle_setup(c)
     g = torch.Generator().manual_seed(1234)
@@ -297,7 +303,7 @@ def cpu_baseline(seconds=18.0):
         pass
     runs = {}
     before = torch.get_num_threads()
-    settings = sorted({1, min(16, allc), allc})
+    settings = sorted({1, min(16, allc)})
     for threads in settings:
         torch.set_num_threads(threads)
         params = mo.init_params(cfg, 0)
@@ -483,12 +489,12 @@ def main():
     fused = dist is None
 
     # ---- the gradient exchange of the N-rank step
-    comm, exchange, why, in_backward = None, "none", "", False
+    comm, rccl, exchange, why, in_backward = None, None, "none", "", False
     if dist is not None:
         exchange = os.environ.get("MOPOE_EXCHANGE", "rccl")
-        if exchange not in ("auto", "xgmi", "rccl"):
-            sys.exit("MOPOE_EXCHANGE must be rccl (default), xgmi or auto")
-        if exchange != "rccl":
+        if exchange not in ("auto", "xgmi", "rccl", "c10d"):
+            sys.exit("MOPOE_EXCHANGE must be rccl (default), c10d, xgmi or auto")
+        if exchange in ("auto", "xgmi"):
             comm, why = open_xgmi(spec.num_floats, device, rank, world, dist)
             if comm is None and exchange == "xgmi":
                 sys.exit("MOPOE_EXCHANGE=xgmi but: " + why)
@@ -500,12 +506,18 @@ def main():
         # replicas start identical (parameters, moments, step counts)
         for t in (eng.params, eng.exp_avg, eng.exp_avg_sq, eng.counters):
             dist.broadcast(t, 0)
+        eng.refresh_wfrag()      # (c10d writes do not bump tensor._version)
+        if exchange == "rccl":
+            rccl = mm.comm.RcclComm()
 
     def step(i):
         # the step's scalar log lands in a ring of pinned host buffers, written
         # by the kernel itself (no copy on the stream)
         if comm is not None and in_backward:
             return eng.train_step(pool[(i * world + rank) % POOL], apply_adam=True, comm=comm,
+                                  stats_host=None if args.no_log_copy else log_ring[i % 8])[1]
+        if rccl is not None:        # ONE host call: backward, ncclAllReduce, Adam
+            return eng.train_step(pool[(i * world + rank) % POOL], apply_adam=True, rccl=rccl,
                                   stats_host=None if args.no_log_copy else log_ring[i % 8])[1]
         plan, ws = eng.train_step(pool[(i * world + rank) % POOL], apply_adam=fused,
                                   stats_host=None if args.no_log_copy else log_ring[i % 8])
@@ -564,7 +576,7 @@ def main():
             why = "timed region over xGMI invalid (%d timeouts, replicas differ: %s); " \
                   "re-run over RCCL" % (int(bad[0].item()), bool(bad[1].item()))
             comm.close()
-            comm, exchange = None, "rccl"
+            comm, exchange = None, "c10d"
             eng.recover()
             eng.reset_parameters(torch.Generator().manual_seed(0))
             eng.exp_avg.zero_()
@@ -609,11 +621,17 @@ def main():
                                          comm is not None and in_backward else
                                          "one launch per rank over xGMI peer windows: push "
                                          "to every peer, rank-ordered sum, Adam"),
-                                "rccl": "RCCL all_reduce of the flat gradient buffer + Adam "
-                                        "kernel (mean, ranks' modality check)"
+                                "rccl": "ONE host call per step (mopoe_rccl_train_step): "
+                                        "backward, ncclAllReduce of the flat gradient buffer "
+                                        "over the library's own RCCL communicator, Adam "
+                                        "kernel (mean, the ranks' modality / validity check)",
+                                "c10d": "three host calls per step: train_step, "
+                                        "torch.distributed all_reduce (RCCL), adam_step"
                                 }[exchange] + (" [%s]" % why if why else ""),
                    "host_log_every_step": not args.no_log_copy,
                    "settle_steps": SETTLE,
+                   # `value` is the SECOND timing of the same W + K steps: what ran before it
+                   "warmup_effective": 2 * args.warmup + args.steps + SETTLE,
                    "final_loss": round(loss, 3)},
         "cold_start": {"ms_per_step": round(1e3 * cold["dt"] / args.steps, 5),
                        "value": round(BATCH * world * args.steps / cold["dt"], 1),
@@ -658,6 +676,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     if comm is not None:
         comm.close()
+    if rccl is not None:
+        rccl.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -28,13 +28,14 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 8
+#define MOPOE_ABI_VERSION 9
 #define MOPOE_MAX_MODS 5      /* modalities                                   */
 #define MOPOE_MAX_SUBSETS 31  /* 2^MAX_MODS - 1 non-empty subsets             */
 #define MOPOE_MAX_JOBS 10     /* decoder passes: 1 joint + 1 unimodal per mod */
 #define MOPOE_HIDDEN 256      /* networks/networks.py:14,50 (hard-coded)      */
 #define MOPOE_MAX_RANKS 8     /* GPUs of one node (xGMI full mesh)            */
 #define MOPOE_IPC_HANDLE_BYTES 64
+#define MOPOE_RCCL_ID_BYTES 128 /* ncclUniqueId                                  */
 #define MOPOE_ROWS 16         /* batch rows per MFMA tile; a row group has <= 16 */
 
 #define MOPOE_ERR_ARG (-1)
@@ -76,6 +77,12 @@ extern "C" {
                                      non-zero no Adam update is applied; the caller
                                      reads it (or its mirror in status_host), raises,
                                      and re-zeroes `partials` and this word to go on */
+#define MOPOE_CTR_FIRST_INVALID 3 /* training step (value of MOPOE_CTR_STEPS_BEGUN) at which
+                                     MOPOE_CTR_INVALID went up, 0 while it is down: the
+                                     steps from this one on were NOT applied -- the caller
+                                     re-arms (zeroes both words and `partials`) and runs
+                                     those batches again (run_epochs.py:180-182 applies a
+                                     step or nothing; ABI 9)                            */
 #define MOPOE_CTR_ADAM_STEPS 4    /* + modality: Adam updates applied to that
                                      modality's parameters (torch.optim.Adam keeps
                                      state['step'] per parameter and skips parameters
@@ -118,8 +125,11 @@ typedef struct mopoe_model {
     int32_t off_lvo[MOPOE_MAX_MODS];
     int32_t off_ctrl;                  /* 64 control words behind the last segment: in
                                           buf->grads, word m = 1.0 if modality m was in
-                                          the step's batch (summed by the ranks'
-                                          all-reduce, checked by the Adam kernel)    */
+                                          the step's batch, word MOPOE_MAX_MODS = 1.0 if
+                                          this rank's backward could not be completed
+                                          (MOPOE_CTR_INVALID) -- summed by the ranks'
+                                          all-reduce, checked by the Adam kernel: no rank
+                                          applies a step that one rank could not finish  */
     int32_t num_floats;                /* length of the flat buffer            */
 } mopoe_model;
 
@@ -230,8 +240,9 @@ typedef struct mopoe_buffers {
     int32_t* status_host;                /* optional: pinned HOST memory (4 int32):
                                             the last kernel of every training step
                                             writes {steps done, MOPOE_CTR_INVALID,
-                                            0, 0} there, so the caller can notice an
-                                            invalid step without synchronising    */
+                                            MOPOE_CTR_FIRST_INVALID, 0} there, so the
+                                            caller can notice an invalid step without
+                                            synchronising                          */
 
     float* g_xhat[MOPOE_MAX_MODS];       /* (R_m, d_m)   d loss / d loc        */
     float* g_heads[MOPOE_MAX_MODS];      /* (n, nh_m)                          */
@@ -268,12 +279,17 @@ typedef struct mopoe_adam {
 #define MOPOE_KERNEL_ADAM 3
 #define MOPOE_KERNEL_FINALIZE 4
 #define MOPOE_KERNEL_FUSED 5   /* encoder layer + per-sample chain in one launch */
-#define MOPOE_KERNEL_XGMI 6    /* gradient exchange over xGMI + Adam in one launch */
-#define MOPOE_NUM_KERNELS 7
+#define MOPOE_KERNEL_XGMI 6    /* gradient exchange over xGMI peer windows            */
+#define MOPOE_KERNEL_RCCL 7    /* RCCL's all-reduce (mopoe_rccl_*), as enqueued       */
+#define MOPOE_NUM_KERNELS 8
 int mopoe_profile_enable(int enable);
 int mopoe_profile_read(int32_t* count, float* total_ms);
 
 int mopoe_abi_version(void);
+/* The library reads its environment knobs (MOPOE_NO_FUSE, MOPOE_QUAD, ... -- test and
+ * experiment switches between launch forms that compute the same bits) once, when it is
+ * loaded: a training step makes no getenv call.  This re-reads them (tests only). */
+int mopoe_reload_knobs(void);
 const char* mopoe_last_error(void);
 /* sizeof / offsetof probes so a binding can verify its struct mirrors:
  * 0 mopoe_model, 1 mopoe_step, 2 mopoe_buffers, 3 mopoe_adam (sizes);
@@ -341,21 +357,29 @@ int mopoe_adam_step(const mopoe_model* model, int32_t present_mask,
  *   mopoe_comm_connect  ... and passes all `world` of them (rank order).
  *   mopoe_comm_allreduce_adam
  *                       replaces `all_reduce(grads); mopoe_adam_step(1/world)`:
- *                       ONE launch that pushes buf->grads to every peer over its
- *                       xGMI link, waits (bounded by timeout_ms) for the peers'
- *                       pushes, sums the copies in rank order (bit-identical on all
- *                       ranks), leaves the sum in buf->grads and applies Adam with
- *                       the mean.  All ranks must call it the same number of times.
+ *                       one launch pushes buf->grads to every peer over its xGMI
+ *                       link, waits (bounded by timeout_ms) for the peers' pushes,
+ *                       sums the copies in rank order (bit-identical on all ranks)
+ *                       and leaves the sum in buf->grads; the Adam launch behind it
+ *                       applies the mean -- or NOTHING when any block's exchange was
+ *                       not good (a wait out of budget, a peer with other
+ *                       modalities): MOPOE_CTR_INVALID is raised and parameters and
+ *                       moments stay at the last complete step.  A time-out is seen
+ *                       by the rank that waited, not necessarily by its peers: after
+ *                       one, re-arm AND re-broadcast params / exp_avg / exp_avg_sq /
+ *                       counters from one rank (every rank holds a whole step, the
+ *                       ranks may be one step apart).  All ranks must call it the
+ *                       same number of times.
  *   mopoe_comm_train_step
  *                       replaces `mopoe_train_step(adam = NULL); all_reduce(grads);
  *                       mopoe_adam_step(1/world)`: mopoe_train_step whose
  *                       weight-gradient launch exchanges every 32x32 gradient block
- *                       with the peers (push, flag, wait, rank-ordered sum) between
- *                       computing it and applying Adam with the mean -- the N-rank
- *                       step has the same two launches as the one-rank step.  All
- *                       ranks must step on batches with the SAME present_mask and the
- *                       same batch-size class (n <= 512 or not): the blocks of the
- *                       launch are matched by index.  buf->grads receives the sum.
+ *                       with the peers (push, flag, wait, rank-ordered sum) and
+ *                       leaves the sum in buf->grads, followed by the Adam launch as
+ *                       above (the whole step or none of it).  All ranks must step on
+ *                       batches with the SAME present_mask and the same batch-size
+ *                       class (n <= 512 or not): the blocks of the launch are matched
+ *                       by index.
  *   mopoe_comm_allreduce
  *                       the same exchange without the update: data (num_floats) is
  *                       replaced by the rank-ordered sum.
@@ -376,6 +400,38 @@ int mopoe_comm_train_step(mopoe_comm* comm, const mopoe_model* model,
                           const mopoe_adam* adam, void* stream);
 int mopoe_comm_status(mopoe_comm* comm, int32_t* timeouts);
 int mopoe_comm_destroy(mopoe_comm* comm);
+
+/* ---------------------------------------------------------------------------
+ * The data-parallel step over RCCL as ONE call (ABI 9; SURVEY.md section 8e: "one
+ * all-reduce (sum, then x 1/world) of the flat fp32 gradient buffer per step", feeding
+ * the optimizer step of experiment.py:256-279).  librccl is bound at run time (dlopen;
+ * inside a PyTorch process: the instance torch has loaded), the communicator is the
+ * library's own:
+ *
+ *   mopoe_rccl_unique_id   ncclGetUniqueId on ONE rank; the caller hands the
+ *                          MOPOE_RCCL_ID_BYTES to the other ranks out of band (e.g.
+ *                          torch.distributed.broadcast) ...
+ *   mopoe_rccl_create      ... and every rank calls this (ncclCommInitRank: collective,
+ *                          the current HIP device is the rank's GPU).
+ *   mopoe_rccl_train_step  replaces `mopoe_train_step(adam = NULL); all_reduce(grads);
+ *                          mopoe_adam_step(world)` by one host call: forward + backward,
+ *                          ncclAllReduce (sum) of buf->grads -- all num_floats, control
+ *                          words included -- and the Adam launch with 1 / world, enqueued
+ *                          back to back on `stream`.  No rank applies a step whose batch
+ *                          held other modalities on some rank or that some rank could not
+ *                          complete; every rank then raises MOPOE_CTR_INVALID at the same
+ *                          step (MOPOE_CTR_FIRST_INVALID), so all ranks can re-arm and run
+ *                          the same batches again.
+ *   mopoe_rccl_allreduce   the plain in-place sum of `count` floats.
+ *   mopoe_rccl_destroy     ncclCommDestroy.
+ * ------------------------------------------------------------------------- */
+typedef struct mopoe_rccl mopoe_rccl;
+int mopoe_rccl_unique_id(void* id_out);
+int mopoe_rccl_create(int32_t rank, int32_t world, const void* id, mopoe_rccl** comm);
+int mopoe_rccl_train_step(mopoe_rccl* comm, const mopoe_model* model, const mopoe_step* step,
+                          const mopoe_buffers* buf, const mopoe_adam* adam, void* stream);
+int mopoe_rccl_allreduce(mopoe_rccl* comm, float* data, int64_t count, void* stream);
+int mopoe_rccl_destroy(mopoe_rccl* comm);
 
 /* Free functions of section 8b, float32 device tensors. */
 

@@ -14,3 +14,34 @@ def pytest_configure(config):
         "markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line(
         "markers", "reference: needs /root/reference (development container only)")
+
+
+@pytest.fixture(autouse=True)
+def _mopoe_knobs(monkeypatch):
+    """libmopoe_hip.so reads its environment knobs (MOPOE_NO_FUSE, MOPOE_QUAD, ...) ONCE;
+    the tests that switch launch forms inside one process go through monkeypatch: every
+    MOPOE_* change re-reads them (mopoe_reload_knobs), and every test starts from the
+    environment as it is."""
+    from importlib import import_module
+    try:
+        L = import_module("2022_cambroise_interpret_multivae_amd._lib")
+    except ImportError:
+        yield
+        return
+    L.reload_knobs()
+    real_set, real_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, *a, **k):
+        real_set(name, value, *a, **k)
+        if name.startswith("MOPOE_"):
+            L.reload_knobs()
+
+    def delenv(name, *a, **k):
+        real_del(name, *a, **k)
+        if name.startswith("MOPOE_"):
+            L.reload_knobs()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield
+    monkeypatch.undo()
+    L.reload_knobs()

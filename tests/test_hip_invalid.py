@@ -51,11 +51,13 @@ def test_timed_out_handoff_applies_nothing_and_raises():
     torch.cuda.synchronize()
     before, steps_before = _state(eng)
     os.environ["MOPOE_TEST_HANDOFF_SPINS"] = "0"     # every row group gives up at once
+    L.reload_knobs()
     try:
         eng.train_step(bx, eps=ex)
         torch.cuda.synchronize()
     finally:
         del os.environ["MOPOE_TEST_HANDOFF_SPINS"]
+        L.reload_knobs()
     after, steps_after = _state(eng)
     for a, b in zip(before, after):
         assert torch.equal(a, b)                     # nothing was applied
