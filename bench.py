@@ -132,12 +132,15 @@ def kernel_models(spec, n, fused_adam, world=1):
     return out
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, cfg="C1"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs,
-    gfx950 correction applied; configs[1]); None if no summary is there."""
+    (profiles/*_pmc_traffic[_<config>].json: FETCH_SIZE and WRITE_SIZE collected in separate
+    runs of `bench.py --config <config>`, gfx950 correction applied); None if no summary of
+    that configuration is there."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_%s.json" % cfg)))
+    if not files and cfg == "C1":
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
         return None
     try:
@@ -153,7 +156,7 @@ def make_pool(c, device, count=POOL, seed=1234):
              for n, d in zip(c["names"], c["dims"])} for _ in range(count)]
 
 
-def roofline_of(spec, n, prof, dt_per_step, fused_adam, world, traffic=True):
+def roofline_of(spec, n, prof, dt_per_step, fused_adam, world, traffic="C1"):
     """The roofline object for the kernel with the largest share of device time."""
     models = kernel_models(spec, n, fused_adam, world)
     total_ms = sum(ms for _, ms in prof.values()) or 1.0
@@ -183,7 +186,7 @@ def roofline_of(spec, n, prof, dt_per_step, fused_adam, world, traffic=True):
         achieved = km["bytes"] / avg_s / 1e9
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS,
                 "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 5)}
-    roof.update({"traffic": pmc_traffic(name) if traffic else None, "kernel": name,
+    roof.update({"traffic": pmc_traffic(name, traffic) if traffic else None, "kernel": name,
                  "avg_us": round(avg_s * 1e6, 3),
                  "share_of_device_time": round(ms / total_ms, 3),
                  "kernels_avg_us": {k: round(v, 3) for k, v in avg_us.items()},
@@ -235,7 +238,7 @@ def other_config(key, device, steps=1000, warmup=300):
     return {"workload": c["label"], "value": round(c["batch"] * steps / dt, 1),
             "unit": "samples/s", "ms_per_step": round(1e3 * dt / steps, 5), "steps": steps,
             "warmup": warmup, "dtype": "f32", "final_loss": round(loss, 3),
-            "roofline": roofline_of(spec, c["batch"], prof, dt / steps, True, 1, traffic=False)}
+            "roofline": roofline_of(spec, c["batch"], prof, dt / steps, True, 1, traffic=key)}
 
 
 def regime_point(device, n=65536):
@@ -457,6 +460,9 @@ def main():
     ap.add_argument("--quick", action="store_true",
                     help="headline + roofline + cpu_baseline only (no other "
                          "configs / regime / eager legs)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C1",
+                    help="the configuration the main loop runs (profiling: tools/"
+                         "profile_round.sh); the metric is quoted on C1 = configs[1]")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearse the multi-GPU step (process group, all-reduce, separate "
                          "Adam kernel) even with one rank")
@@ -478,7 +484,7 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    c = CONFIGS["C1"]
+    c = CONFIGS[args.config]
     BATCH = c["batch"]
     spec = make_spec(c)
     eng = mm.MoPoEEngine(spec, device, seed=1234)
@@ -660,7 +666,7 @@ def main():
             steady = min(steady, cold["settle_dt"] / SETTLE)
         out["roofline"] = roofline_of(spec, BATCH, prof,
                                       steady if (dist is None and fused) else None,
-                                      fused or in_backward, world)
+                                      fused or in_backward, world, traffic=args.config)
     elif dist is not None and not args.no_roofline:
         for i in range(args.steps):   # keep the collectives matched
             step(nxt + i)
