@@ -541,6 +541,7 @@ def main():
             torch.cuda.synchronize()
 
     def timed(warmup, steps, first=0):
+        ws = None
         for i in range(warmup):
             step(first + i)
         barrier()

@@ -95,6 +95,33 @@ CASES += [
          steps=1, full=True, likelihood="laplace"),
 ]
 
+# The topologies workflow.train_exp exposes beyond its defaults (networks.py:16-20,51-59,
+# 66-77): more hidden encoder layers (or none), hidden decoder layers, Dropout behind every
+# hidden layer (keep masks recorded like eps), the per-subject output scale head.
+CASES += [
+    dict(case="t_enc2_dec1_n32", **C1, method="joint_elbo", factorized=True, N=32, steps=3,
+         full=True, enc_layers=2, dec_layers=1),
+    dict(case="t_enc2_dec1_drop_n32", **C1, method="joint_elbo", factorized=True, N=32,
+         steps=3, full=True, enc_layers=2, dec_layers=1, dropout=0.2),
+    dict(case="t_sample_scale_n32", **C1, method="joint_elbo", factorized=True, N=32,
+         steps=2, full=True, sample_scale=True),
+    dict(case="t_sample_scale_dec2_drop_n24", **C1, method="joint_elbo", factorized=False,
+         N=24, steps=2, full=True, dec_layers=2, dropout=0.1, sample_scale=True),
+    dict(case="t_enc0_n24", **C1, method="joint_elbo", factorized=True, N=24, steps=2,
+         full=True, enc_layers=0),
+    dict(case="t_poe_enc2_dec1_drop_n19", **C1, method="poe", factorized=True, N=19, steps=2,
+         full=True, enc_layers=2, dec_layers=1, dropout=0.25),
+    dict(case="t_moe_enc3_n21", **C1, method="moe", factorized=True, N=21, steps=1,
+         full=True, enc_layers=3, dec_layers=1, likelihood="laplace"),
+    dict(case="t_c5_enc3_dec2_drop_n20", **C5, method="joint_elbo", factorized=True, N=20,
+         steps=2, full=True, enc_layers=3, dec_layers=2, dropout=0.15),
+    dict(case="t_c5_missing_enc2_dec1_n20", **C5, method="joint_elbo", factorized=True, N=20,
+         steps=1, full=True, enc_layers=2, dec_layers=1, dropout=0.2,
+         present=["rois", "tracts"]),
+    dict(case="t_enc2_dec1_drop_n256", **C1, method="joint_elbo", factorized=True, N=256,
+         steps=3, full=False, enc_layers=2, dec_layers=1, dropout=0.2),
+]
+
 # forward-only variants (BaseMMVae.forward flags), on the c1 model
 FWD_CASES = [
     dict(case="fwd_c1_nosample_n16", **C1, method="joint_elbo",
@@ -139,17 +166,18 @@ def checksum(t):
 
 
 def build(ns, c, seed=0):
+    topo = {k: c[k] for k in ("enc_layers", "dec_layers", "dropout", "sample_scale") if k in c}
     flags = rh.make_flags(c["input_dim"],
                           mo.Config(c["names"], c["input_dim"], c["style_dim"],
                                     factorized=c["factorized"]).style_dim,
                           method=c["method"], factorized=c["factorized"],
                           poe_unimodal_elbos=c.get("poe_unimodal_elbos", True),
-                          likelihood=c.get("likelihood", "normal"))
+                          likelihood=c.get("likelihood", "normal"), **topo)
     exp = rh.build_experiment(ns, flags, c["names"])
     cfg = mo.Config(c["names"], c["input_dim"], c["style_dim"],
                     method=c["method"], factorized=c["factorized"],
                     poe_unimodal_elbos=c.get("poe_unimodal_elbos", True),
-                    likelihood=c.get("likelihood", "normal"))
+                    likelihood=c.get("likelihood", "normal"), **topo)
     init = mo.init_params(cfg, seed)
     missing, unexpected = exp.models.load_state_dict(init, strict=True)
     assert not missing and not unexpected
@@ -211,6 +239,7 @@ def run_case(ns, c):
             store["in/x/" + k] = np32(v)
     for step in range(c["steps"]):
         tape = rh.NoiseTape(model, generator=mo.noise_rng(4321 + step))
+        masks = rh.MaskTape(model, generator=mo.noise_rng(8765 + step))
         present = c["present_steps"][step] if "present_steps" in c else list(x)
         batch = (OrderedDict((k, v.double()) for k, v in x.items() if k in present),
                  None, {})
@@ -219,6 +248,11 @@ def run_case(ns, c):
             store["noise_checksum/%d/%d" % (step, i)] = checksum(e)
             if c["full"]:
                 store["noise/%d/%d" % (step, i)] = np32(e)
+        for i, e in enumerate(masks.tape):      # dropout keep masks, bit-packed
+            store["mask_checksum/%d/%d" % (step, i)] = checksum(e)
+            if c["full"]:
+                store["mask/%d/%d" % (step, i)] = np.packbits(e.numpy().astype(np.uint8))
+                store["mask_shape/%d/%d" % (step, i)] = np.array(e.shape)
         opt.zero_grad()
         out["total_loss"].backward()
         if step == 0:

@@ -37,8 +37,15 @@ class Config:
                  method="joint_elbo", factorized=True, beta=1.0,
                  beta_style=1.0, beta_content=1.0, initial_out_logvar=-3.0,
                  learn_output_scale=True, lr=0.002, betas=(0.9, 0.999),
-                 adam_eps=1e-8, poe_unimodal_elbos=True, likelihood="normal"):
+                 adam_eps=1e-8, poe_unimodal_elbos=True, likelihood="normal",
+                 enc_layers=1, dec_layers=0, dropout=0.0, sample_scale=False):
         assert method in ("joint_elbo", "poe", "moe")
+        # experiments/workflow.py:41-49: num_hidden_layer_encoder / _decoder, dropout_rate,
+        # out_scale_per_subject (-> flags.learn_output_sample_scale, workflow.py:112)
+        self.enc_layers = int(enc_layers)
+        self.dec_layers = int(dec_layers)
+        self.dropout = float(dropout)
+        self.sample_scale = bool(sample_scale)
         # experiments/modalities/modality.py:18-30: the decoder's (loc, scale) pair feeds
         # torch.distributions.Normal or Laplace (Bernoulli / OneHotCategorical take other
         # arguments than the pair this decoder returns)
@@ -101,23 +108,37 @@ def param_shapes(cfg):
     for m, name in enumerate(cfg.names):
         d, s = cfg.input_dim[m], cfg.style_dim[m]
         e = "encoders.%s." % name
-        shapes[e + "shared_encoder.0.weight"] = (HIDDEN, d)
-        shapes[e + "shared_encoder.0.bias"] = (HIDDEN,)
-        shapes[e + "class_mu.weight"] = (D, HIDDEN)
+        width = d
+        # nn.Sequential of (Linear, ReLU, Dropout) triples: layer l is module 3 l
+        for l in range(cfg.enc_layers):
+            shapes[e + "shared_encoder.%d.weight" % (3 * l)] = (HIDDEN, width)
+            shapes[e + "shared_encoder.%d.bias" % (3 * l)] = (HIDDEN,)
+            width = HIDDEN
+        shapes[e + "class_mu.weight"] = (D, width)
         shapes[e + "class_mu.bias"] = (D,)
-        shapes[e + "class_logvar.weight"] = (D, HIDDEN)
+        shapes[e + "class_logvar.weight"] = (D, width)
         shapes[e + "class_logvar.bias"] = (D,)
         if cfg.has_style(m):
-            shapes[e + "style_mu.weight"] = (s, HIDDEN)
+            shapes[e + "style_mu.weight"] = (s, width)
             shapes[e + "style_mu.bias"] = (s,)
-            shapes[e + "style_logvar.weight"] = (s, HIDDEN)
+            shapes[e + "style_logvar.weight"] = (s, width)
             shapes[e + "style_logvar.bias"] = (s,)
     for m, name in enumerate(cfg.names):
         d, s = cfg.input_dim[m], cfg.style_dim[m]
         k = "decoders.%s." % name
-        shapes[k + "logvar"] = (1, d)
-        shapes[k + "out_mu.weight"] = (d, s + D)
+        # (a module's own parameters come before its sub-modules' in state_dict order)
+        if not cfg.sample_scale:
+            shapes[k + "logvar"] = (1, d)
+        width = s + D
+        for l in range(cfg.dec_layers):
+            shapes[k + "shared_decoder.%d.weight" % (3 * l)] = (HIDDEN, width)
+            shapes[k + "shared_decoder.%d.bias" % (3 * l)] = (HIDDEN,)
+            width = HIDDEN
+        shapes[k + "out_mu.weight"] = (d, width)
         shapes[k + "out_mu.bias"] = (d,)
+        if cfg.sample_scale:        # networks.py:58-59: a Linear head instead of the parameter
+            shapes[k + "logvar.weight"] = (d, width)
+            shapes[k + "logvar.bias"] = (d,)
     return shapes
 
 
@@ -237,14 +258,28 @@ def calc_group_divergence_moe(mus, logvars, weights, normalization):
 # --------------------------------------------------------------------------
 # L1 model (networks.py, BaseMMVae.py)
 # --------------------------------------------------------------------------
-def encoder_forward(params, cfg, m, x):
-    """experiments/multimodal_cohort/networks/networks.py:30-36 with one
-    hidden layer and dropout 0: returns (style_mu, style_logvar, class_mu,
-    class_logvar); style is (None, None) when not factorized / style_dim 0."""
+def _hidden_stack(params, prefix, layers, h, cfg, noise, train):
+    """nn.Sequential of `layers` x (Linear, ReLU, Dropout(cfg.dropout))
+    (networks.py:16-20,51-55).  Dropout in training mode is ATen's
+    x * (bernoulli(1 - p) / (1 - p)); the keep masks come off the noise object's
+    mask tape in call order (the reference draws them from torch's global RNG)."""
+    lin = torch.nn.functional.linear
+    for l in range(layers):
+        h = torch.relu(lin(h, params[prefix + "%d.weight" % (3 * l)],
+                           params[prefix + "%d.bias" % (3 * l)]))
+        if train and cfg.dropout > 0.0:
+            keep = noise.keep_mask(h.shape, cfg.dropout)
+            h = h * (keep / (1.0 - cfg.dropout))
+    return h
+
+
+def encoder_forward(params, cfg, m, x, noise=None, train=False):
+    """experiments/multimodal_cohort/networks/networks.py:30-36: returns
+    (style_mu, style_logvar, class_mu, class_logvar, h); style is (None, None)
+    when not factorized / style_dim 0; h = what the heads read."""
     e = "encoders.%s." % cfg.names[m]
     lin = torch.nn.functional.linear
-    h = torch.relu(lin(x, params[e + "shared_encoder.0.weight"],
-                       params[e + "shared_encoder.0.bias"]))
+    h = _hidden_stack(params, e + "shared_encoder.", cfg.enc_layers, x, cfg, noise, train)
     c_mu = lin(h, params[e + "class_mu.weight"], params[e + "class_mu.bias"])
     c_lv = lin(h, params[e + "class_logvar.weight"],
                params[e + "class_logvar.bias"])
@@ -257,17 +292,24 @@ def encoder_forward(params, cfg, m, x):
     return None, None, c_mu, c_lv, h
 
 
-def decoder_forward(params, cfg, m, z_style, z_class):
-    """experiments/multimodal_cohort/networks/networks.py:66-77 with zero
-    hidden layers: (loc, scale) with scale = exp(0.5*logvar), shape (1,d)."""
+def decoder_forward(params, cfg, m, z_style, z_class, noise=None, train=False):
+    """experiments/multimodal_cohort/networks/networks.py:66-77: (loc, scale) with
+    scale = exp(0.5*logvar): the (1, d) parameter, or (N, d) from the Linear head of
+    learn_output_sample_scale."""
     k = "decoders.%s." % cfg.names[m]
     if cfg.has_style(m):
         z = torch.cat((z_style, z_class), dim=1)
     else:
         z = z_class
-    x_hat = torch.nn.functional.linear(z, params[k + "out_mu.weight"],
+    h = _hidden_stack(params, k + "shared_decoder.", cfg.dec_layers, z, cfg, noise, train)
+    x_hat = torch.nn.functional.linear(h, params[k + "out_mu.weight"],
                                        params[k + "out_mu.bias"])
-    return x_hat, (params[k + "logvar"] * 0.5).exp()
+    if cfg.sample_scale:
+        logvar = torch.nn.functional.linear(h, params[k + "logvar.weight"],
+                                            params[k + "logvar.bias"])
+    else:
+        logvar = params[k + "logvar"]
+    return x_hat, (logvar * 0.5).exp()
 
 
 class Noise:
@@ -275,12 +317,28 @@ class Noise:
     (BaseMMVae.py:37-40,143,155-159): content first, then style per present
     modality in `modalities` order; one such group per forward call."""
 
-    def __init__(self, tape=None, generator=None):
+    def __init__(self, tape=None, generator=None, mask_tape=None, mask_generator=None):
         self.tape = [] if tape is None else list(tape)
         self.replay = tape is not None
         self.pos = 0
         self.gen = generator
         self.dtype = torch.float32
+        # dropout keep masks (0 / 1), in the order the Dropout modules run
+        self.mask_tape = [] if mask_tape is None else list(mask_tape)
+        self.mask_replay = mask_tape is not None
+        self.mask_pos = 0
+        self.mask_gen = mask_generator
+
+    def keep_mask(self, shape, p):
+        if self.mask_replay:
+            keep = self.mask_tape[self.mask_pos]
+            assert tuple(keep.shape) == tuple(shape), (keep.shape, shape)
+            self.mask_pos += 1
+        else:
+            keep = torch.from_numpy(
+                (self.mask_gen.random(tuple(shape)) >= p).astype(np.float32))
+            self.mask_tape.append(keep)
+        return keep.to(self.dtype)
 
     def draw(self, shape):
         if self.replay:
@@ -325,14 +383,14 @@ def _fusion_condition(cfg, subset, batch):
     return True
 
 
-def inference(params, cfg, batch, sample=True, use_expert=None):
+def inference(params, cfg, batch, sample=True, use_expert=None, noise=None, train=False):
     """experiments/utils/BaseMMVae.py:181-239 (+ encode :167-178)."""
     enc_mods = OrderedDict()
     hidden = OrderedDict()
     for m, name in enumerate(cfg.names):
         if name in batch:
-            s_mu, s_lv, c_mu, c_lv, h = encoder_forward(params, cfg, m,
-                                                        batch[name])
+            s_mu, s_lv, c_mu, c_lv, h = encoder_forward(params, cfg, m, batch[name],
+                                                        noise, train)
             enc_mods[name + "_style"] = [s_mu, s_lv]
             enc_mods[name] = [c_mu, c_lv]
             hidden[name] = h
@@ -369,10 +427,11 @@ def inference(params, cfg, batch, sample=True, use_expert=None):
             "subsets": distr_subsets, "_hidden": hidden}
 
 
-def forward(params, cfg, batch, noise, sample_latents=True, use_expert=None):
-    """experiments/utils/BaseMMVae.py:137-165.  rec[m] is (loc, scale)."""
+def forward(params, cfg, batch, noise, sample_latents=True, use_expert=None, train=False):
+    """experiments/utils/BaseMMVae.py:137-165.  rec[m] is (loc, scale).  `train`:
+    model.train() -- the Dropout modules are live (run_epochs.py:147)."""
     latents = inference(params, cfg, batch, sample=sample_latents,
-                        use_expert=use_expert)
+                        use_expert=use_expert, noise=noise, train=train)
     results = {"latents": latents, "group_distr": latents["joint"]}
     if sample_latents:
         class_embeddings = reparameterize(latents["joint"][0],
@@ -395,7 +454,7 @@ def forward(params, cfg, batch, noise, sample_latents=True, use_expert=None):
                 z_s = reparameterize(s_mu, s_lv, noise)
             else:
                 z_s = s_mu
-            rec[name] = decoder_forward(params, cfg, m, z_s, class_embeddings)
+            rec[name] = decoder_forward(params, cfg, m, z_s, class_embeddings, noise, train)
             zs[name] = z_s
     results["rec"] = rec
     results["_z_class"] = class_embeddings
@@ -441,11 +500,11 @@ def calc_elbo(cfg, modality, recs, klds, present):
     return rec_error + cfg.beta * div
 
 
-def basic_routine_epoch(params, cfg, batch, noise):
+def basic_routine_epoch(params, cfg, batch, noise, train=False):
     """experiments/run_epochs.py:73-135 (+ calc_log_probs :27-38, calc_klds
     :41-48, calc_klds_style :51-59, calc_style_kld :62-69)."""
     batch = OrderedDict((k, v.to(cfg.dtype)) for k, v in batch.items())
-    results = forward(params, cfg, batch, noise)
+    results = forward(params, cfg, batch, noise, train=train)
     log_probs = OrderedDict()
     weighted_log_prob = 0.0
     for name in cfg.names:
@@ -488,7 +547,7 @@ def basic_routine_epoch(params, cfg, batch, noise):
             klds_joint["style"][name] = kld_style_m
             if not cfg.poe_unimodal_elbos:      # run_epochs.py:115
                 continue
-            r_mod = forward(params, cfg, {name: batch[name]}, noise)
+            r_mod = forward(params, cfg, {name: batch[name]}, noise, train=train)
             loc, scale = r_mod["rec"][name]
             log_prob_mod = -calc_log_prob(loc, scale, batch[name],
                                           len(batch[name]), cfg.likelihood)
@@ -553,7 +612,7 @@ def loss_and_grads(params, cfg, batch, noise):
     for k, v in params.items():
         leaves[k] = v.detach().to(cfg.dtype).clone().requires_grad_(
             trainable(cfg, k))
-    out = basic_routine_epoch(leaves, cfg, batch, noise)
+    out = basic_routine_epoch(leaves, cfg, batch, noise, train=True)
     out["total_loss"].backward()
     grads = OrderedDict((k, v.grad) for k, v in leaves.items()
                         if v.grad is not None)

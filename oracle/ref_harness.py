@@ -105,7 +105,8 @@ def import_reference():
 def make_flags(input_dim, style_dim, class_dim=20, method="joint_elbo",
                factorized=True, beta=1.0, beta_style=1.0, beta_content=1.0,
                batch_size=256, initial_out_logvar=-3.0, learn_output_scale=True,
-               poe_unimodal_elbos=True, likelihood="normal"):
+               poe_unimodal_elbos=True, likelihood="normal", enc_layers=1, dec_layers=0,
+               dropout=0.0, sample_scale=False):
     """SimpleNamespace mirroring what workflow.train_exp builds
     (reference experiments/workflow.py:98-145)."""
     M = len(input_dim)
@@ -115,11 +116,11 @@ def make_flags(input_dim, style_dim, class_dim=20, method="joint_elbo",
         factorized_representation=factorized, input_dim=list(input_dim),
         joint_elbo=(method == "joint_elbo"), modality_jsd=False,
         modality_moe=(method == "moe"), modality_poe=(method == "poe"),
-        poe_unimodal_elbos=poe_unimodal_elbos, num_hidden_layer_encoder=1,
-        num_hidden_layer_decoder=0, dropout_rate=0.0,
+        poe_unimodal_elbos=poe_unimodal_elbos, num_hidden_layer_encoder=enc_layers,
+        num_hidden_layer_decoder=dec_layers, dropout_rate=dropout,
         initial_out_logvar=initial_out_logvar,
         learn_output_scale=learn_output_scale,
-        learn_output_sample_scale=False, likelihood=likelihood,
+        learn_output_sample_scale=sample_scale, likelihood=likelihood,
         style_dim=list(style_dim) if factorized else [0] * M,
         num_models=1, num_mods=M, device=torch.device("cpu"),
         alpha_modalities=[1.0 / (M + 1)] * (M + 1), grad_scaling=False)
@@ -178,3 +179,45 @@ class NoiseTape:
                 tuple(mu.shape)).astype(np.float32))
             self.tape.append(eps)
         return eps.mul(std).add(mu)
+
+
+class _TapeDropout(torch.nn.Module):
+    """Stands in for one nn.Dropout of the reference model: the same arithmetic as ATen's
+    dropout in training mode -- x * (bernoulli(1 - p) / (1 - p)) -- with the keep mask
+    taken from a tape instead of torch's global generator."""
+
+    def __init__(self, p, tape):
+        super().__init__()
+        self.p = p
+        self.tape = tape
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        return x * (self.tape.draw(x.shape, self.p) / (1.0 - self.p))
+
+
+class MaskTape:
+    """Record / replay the dropout keep masks of a reference model, in the order its
+    Dropout modules run (networks.py:19,54).  `generator`: a numpy Generator."""
+
+    def __init__(self, model, generator=None, replay=None):
+        self.tape = [] if replay is None else list(replay)
+        self.replay = replay is not None
+        self.pos = 0
+        self.gen = generator
+        for parent in list(model.modules()):
+            for name, child in list(parent.named_children()):
+                if isinstance(child, (torch.nn.Dropout, _TapeDropout)):
+                    setattr(parent, name, _TapeDropout(child.p, self))
+
+    def draw(self, shape, p):
+        if self.replay:
+            keep = self.tape[self.pos]
+            self.pos += 1
+        else:
+            import numpy as np
+            keep = torch.from_numpy(
+                (self.gen.random(tuple(shape)) >= p).astype(np.float32))
+            self.tape.append(keep)
+        return keep

@@ -34,7 +34,9 @@ class Fixture:
         self.cfg = mo.Config(m["names"], m["input_dim"], m["style_dim"],
                              method=m["method"], factorized=m["factorized"],
                              poe_unimodal_elbos=m.get("poe_unimodal_elbos", True),
-                             likelihood=m.get("likelihood", "normal"))
+                             likelihood=m.get("likelihood", "normal"),
+                             **{k: m[k] for k in ("enc_layers", "dec_layers", "dropout",
+                                                  "sample_scale") if k in m})
         self.N = m["N"]
         self.steps = m.get("steps", 1)
         self.full = m.get("full", True)
@@ -80,8 +82,10 @@ class Fixture:
         return (7 if self.case.startswith("fwd_") else 4321 + step)
 
     def noise(self, step):
-        """mo.Noise that regenerates the fixture's eps stream for `step`."""
-        return mo.Noise(generator=mo.noise_rng(self.noise_seed(step)))
+        """mo.Noise that regenerates the fixture's eps stream (and the stream of its
+        dropout keep masks) for `step`."""
+        return mo.Noise(generator=mo.noise_rng(self.noise_seed(step)),
+                        mask_generator=mo.noise_rng(8765 + step))
 
     def check_noise(self, step, noise):
         for i, e in enumerate(noise.tape):
@@ -91,6 +95,17 @@ class Fixture:
                 cs = self.z["noise_checksum/%d/%d" % (step, i)]
                 f = e.double().reshape(-1)
                 assert abs(f.sum().item() - cs[0]) < 1e-6 * max(1, abs(cs[0]))
+        for i, e in enumerate(noise.mask_tape):      # dropout keep masks (bit-packed)
+            if self.has("mask/%d/%d" % (step, i)):
+                shape = tuple(int(v) for v in self.z["mask_shape/%d/%d" % (step, i)])
+                bits = np.unpackbits(self.z["mask/%d/%d" % (step, i)])[:e.numel()]
+                assert torch.equal(e, torch.from_numpy(bits.astype(np.float32)).reshape(shape))
+            else:
+                assert self.has("mask_checksum/%d/%d" % (step, i)), "more masks than recorded"
+                assert e.double().sum().item() == self.z["mask_checksum/%d/%d" % (step, i)][0]
+        nmask = len([k for k in self.z.files if k.startswith("mask_checksum/%d/" % step)])
+        assert nmask == len(noise.mask_tape), "dropout masks: %d drawn, %d recorded" % (
+            len(noise.mask_tape), nmask)
 
 
 def assert_close(a, b, rtol, atol, what=""):
