@@ -17,6 +17,7 @@ ABI_VERSION = 9
 MAX_RANKS = 8
 IPC_HANDLE_BYTES = 64
 RCCL_ID_BYTES = 128
+MAX_LAYERS = 4
 
 SUB_POE, SUB_POE_PRIOR, SUB_SLICES = 0, 1, 2
 JOINT_MIXTURE, JOINT_MEAN, JOINT_EXPERT = 0, 1, 2
@@ -125,6 +126,36 @@ class Buffers(C.Structure):
     ]
 
 
+class Topology(C.Structure):
+    _fields_ = [
+        ("enc_layers", _i32),
+        ("dec_layers", _i32),
+        ("dropout", _f32),
+        ("sample_scale", _i32),
+        ("off_we", (_i32 * MAX_LAYERS) * MAX_MODS),
+        ("off_be", (_i32 * MAX_LAYERS) * MAX_MODS),
+        ("off_wg", (_i32 * MAX_LAYERS) * MAX_MODS),
+        ("off_bg", (_i32 * MAX_LAYERS) * MAX_MODS),
+        ("off_wlv", _i32 * MAX_MODS),
+        ("off_blv", _i32 * MAX_MODS),
+    ]
+
+
+class GBuffers(C.Structure):
+    _fields_ = [
+        ("enc_act", (_ptr * MAX_LAYERS) * MAX_MODS),
+        ("enc_pre0", _ptr * MAX_MODS),
+        ("dec_act", (_ptr * MAX_LAYERS) * MAX_MODS),
+        ("g_enc", (_ptr * MAX_LAYERS) * MAX_MODS),
+        ("g_dec", (_ptr * MAX_LAYERS) * MAX_MODS),
+        ("lv", _ptr * MAX_MODS),
+        ("g_lv", _ptr * MAX_MODS),
+        ("g_z", _ptr * MAX_MODS),
+        ("keep_enc", (_ptr * MAX_LAYERS) * MAX_MODS),
+        ("keep_dec", (_ptr * MAX_LAYERS) * MAX_MODS),
+    ]
+
+
 class Adam(C.Structure):
     _fields_ = [("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32)]
 
@@ -162,6 +193,15 @@ SYMBOLS = {
                                         C.POINTER(Buffers), C.POINTER(Adam), _ptr]),
     "mopoe_comm_status": (C.c_int, [_ptr, C.POINTER(_i32)]),
     "mopoe_comm_destroy": (C.c_int, [_ptr]),
+    "mopoe_topology_layout": (C.c_int, [C.POINTER(Model), C.POINTER(Topology)]),
+    "mopoe_general_enc_blocks": (C.c_int, [C.POINTER(Topology), C.POINTER(Step), C.c_int]),
+    "mopoe_general_forward": (C.c_int, [C.POINTER(Model), C.POINTER(Topology), C.POINTER(Step),
+                                        C.POINTER(Buffers), C.POINTER(GBuffers), _ptr]),
+    "mopoe_general_train_step": (C.c_int, [C.POINTER(Model), C.POINTER(Topology),
+                                           C.POINTER(Step), C.POINTER(Buffers),
+                                           C.POINTER(GBuffers), C.POINTER(Adam), _ptr, _ptr]),
+    "mopoe_general_adam_step": (C.c_int, [C.POINTER(Model), C.POINTER(Topology), _i32,
+                                          C.POINTER(Buffers), C.POINTER(Adam), _i32, _ptr]),
     "mopoe_rccl_unique_id": (C.c_int, [_ptr]),
     "mopoe_rccl_create": (C.c_int, [_i32, _i32, _ptr, C.POINTER(_ptr)]),
     "mopoe_rccl_train_step": (C.c_int, [_ptr, C.POINTER(Model), C.POINTER(Step),
@@ -200,7 +240,8 @@ def _load():
                C.sizeof(Adam), Step.job_eps_content.offset,
                Step.comp_w.offset, Buffers.partials.offset,
                Model.num_floats.offset, Buffers.status_host.offset,
-               Model.off_ctrl.offset, Buffers.wfrag.offset]
+               Model.off_ctrl.offset, Buffers.wfrag.offset, C.sizeof(Topology),
+               C.sizeof(GBuffers), GBuffers.keep_enc.offset]
     for which, mine in enumerate(mirrors):
         if lib.mopoe_sizeof(which) != mine:
             raise ImportError("ctypes mirror %d disagrees with the C struct "

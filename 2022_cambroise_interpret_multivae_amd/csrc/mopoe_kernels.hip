@@ -2288,10 +2288,38 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w, const XgPeer
     if (xg) w.xg = *xg;
 }
 
+bool default_topology(const mopoe_topology* tp);
+
+// `tp`: the model's topology (nullptr / the default one: the layout of mopoe_model_layout).
+// A modality's encoder parameters are one contiguous run of the flat buffer and so are its
+// decoder's (mopoe_topology_layout keeps it that way): two segments per modality.
 int build_adam_segs(const mopoe_model& mdl, int32_t present_mask, const mopoe_adam& adam,
-                    int32_t world, AdamSegs& sg) {
+                    int32_t world, AdamSegs& sg, const mopoe_topology* tp = nullptr) {
     memset(&sg, 0, sizeof(sg));
     if (world < 1) return fail(MOPOE_ERR_ARG, "world must be >= 1%s");
+    if (!default_topology(tp)) {
+        for (int m = 0; m < mdl.num_mods; ++m) {
+            if (!((present_mask >> m) & 1)) continue;
+            const int d = mdl.input_dim[m];
+            sg.seg_mod[sg.nseg] = m;
+            sg.wf_src[sg.nseg] = -1;
+            sg.begin[sg.nseg] = tp->enc_layers > 0 ? tp->off_we[m][0] : mdl.off_wh[m];
+            sg.end[sg.nseg++] = mdl.off_bh[m] + heads_dim(mdl, m);
+            sg.seg_mod[sg.nseg] = m;
+            sg.wf_src[sg.nseg] = -1;
+            sg.begin[sg.nseg] = tp->dec_layers > 0 ? tp->off_wg[m][0] : mdl.off_wd[m];
+            sg.end[sg.nseg++] = tp->sample_scale ? tp->off_blv[m] + d
+                                : mdl.learn_output_scale ? mdl.off_lvo[m] + d : mdl.off_bd[m] + d;
+        }
+        if (sg.nseg == 0) return fail(MOPOE_ERR_ARG, "empty present_mask%s");
+        sg.num_mods = mdl.num_mods;
+        sg.present_mask = present_mask;
+        sg.world = world;
+        sg.off_ctrl = mdl.off_ctrl;
+        sg.grad_scale = 1.0f / (float)world;
+        sg.adam = adam;
+        return 0;
+    }
     const WFrag wf = wfrag_layout(mdl);
     sg.wf_total = wf.total;
     for (int m = 0; m < mdl.num_mods; ++m) {
@@ -2334,11 +2362,12 @@ int comm_world(const mopoe_comm* c);
 // modality masks and invalid flags: adam_step_valid); false when the exchange compared the
 // masks itself (the xGMI forms: the masks travel in the arrival flags).
 int launch_adam(const mopoe_model& mdl, int32_t present_mask, const mopoe_buffers& buf,
-                const mopoe_adam& adam, int32_t world, bool ctrl_check, hipStream_t s) {
+                const mopoe_adam& adam, int32_t world, bool ctrl_check, hipStream_t s,
+                const mopoe_topology* tp = nullptr) {
     if (!buf.params || !buf.grads || !buf.exp_avg || !buf.exp_avg_sq || !buf.counters)
         return fail(MOPOE_ERR_ARG, "null optimiser buffer%s");
     AdamSegs sg;
-    if (int rc = build_adam_segs(mdl, present_mask, adam, world, sg)) return rc;
+    if (int rc = build_adam_segs(mdl, present_mask, adam, world, sg, tp)) return rc;
     if (!ctrl_check) sg.world = 1;   // (grad_scale stays 1 / world)
     {
         ProfScope ps(MOPOE_KERNEL_ADAM, s);
@@ -2412,6 +2441,8 @@ int launch_wfrag(const mopoe_model& mdl, const mopoe_buffers& buf, hipStream_t s
     return check_launch("k_wfrag");
 }
 
+#include "mopoe_general.inc"
+
 }  // namespace
 
 #include "mopoe_xgmi.inc"
@@ -2453,6 +2484,81 @@ int mopoe_model_layout(mopoe_model* mdl) {
     return 0;
 }
 
+// Layout of a general topology (mopoe_topology): per modality the encoder's parameters in
+// one run -- hidden layers, then the heads -- and the decoder's in another -- hidden layers,
+// out_mu, then the logvar parameter or the logvar head.  The default topology gives exactly
+// mopoe_model_layout's offsets.
+int mopoe_topology_layout(mopoe_model* mdl, mopoe_topology* tp) {
+    if (!mdl || !tp) return fail(MOPOE_ERR_ARG, "null model%s");
+    if (mdl->num_mods < 1 || mdl->num_mods > MOPOE_MAX_MODS)
+        return fail(MOPOE_ERR_ARG, "num_mods out of range%s");
+    if (int rc = default_topology(tp) ? 0 : validate_topology(*mdl, *tp)) return rc;
+    int off = 0;
+    auto seg = [&off](int count) {
+        const int o = off;
+        off += round_up(count, 64);
+        return o;
+    };
+    for (int m = 0; m < MOPOE_MAX_MODS; ++m)
+        for (int l = 0; l < MOPOE_MAX_LAYERS; ++l)
+            tp->off_we[m][l] = tp->off_be[m][l] = tp->off_wg[m][l] = tp->off_bg[m][l] = 0;
+    for (int m = 0; m < mdl->num_mods; ++m) {
+        const int d = mdl->input_dim[m], nh = heads_dim(*mdl, m), zd = z_dim(*mdl, m);
+        if (d < 1 || mdl->style_dim[m] < 0) return fail(MOPOE_ERR_ARG, "bad modality dims%s");
+        for (int l = 0; l < tp->enc_layers; ++l) {
+            tp->off_we[m][l] = seg(kHid * (l == 0 ? d : kHid));
+            tp->off_be[m][l] = seg(kHid);
+        }
+        mdl->off_w1[m] = tp->off_we[m][0];
+        mdl->off_b1[m] = tp->off_be[m][0];
+        mdl->off_wh[m] = seg(nh * (tp->enc_layers > 0 ? kHid : d));
+        mdl->off_bh[m] = seg(nh);
+        for (int l = 0; l < tp->dec_layers; ++l) {
+            tp->off_wg[m][l] = seg(kHid * (l == 0 ? zd : kHid));
+            tp->off_bg[m][l] = seg(kHid);
+        }
+        const int dw = tp->dec_layers > 0 ? kHid : zd;
+        mdl->off_wd[m] = seg(d * dw);
+        mdl->off_bd[m] = seg(d);
+        mdl->off_lvo[m] = off;   // (with the logvar head: no parameter, the offset stays readable)
+        tp->off_wlv[m] = tp->off_blv[m] = off;
+        if (tp->sample_scale) {
+            tp->off_wlv[m] = seg(d * dw);
+            tp->off_blv[m] = seg(d);
+        } else {
+            mdl->off_lvo[m] = seg(d);
+        }
+    }
+    mdl->off_ctrl = seg(64);
+    mdl->num_floats = off;
+    return 0;
+}
+
+int mopoe_general_enc_blocks(const mopoe_topology* tp, const mopoe_step* st, int train) {
+    if (!tp || !st) return 1;
+    return general_enc_blocks(*tp, *st, train != 0);
+}
+
+int mopoe_general_forward(const mopoe_model* mdl, const mopoe_topology* tp, const mopoe_step* st,
+                          const mopoe_buffers* buf, const mopoe_gbuffers* gb, void* stream) {
+    GArgs ga;
+    GeneralPlan gp;
+    if (int rc = general_args(mdl, tp, st, buf, gb, false, ga, gp)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = general_forward_part(ga, gp, nullptr, s)) return rc;
+    {
+        ProfScope ps(MOPOE_KERNEL_FINALIZE, s);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, ga.ka);
+    }
+    return check_launch("k_finalize");
+}
+
+int mopoe_general_adam_step(const mopoe_model* mdl, const mopoe_topology* tp, int32_t present_mask,
+                            const mopoe_buffers* buf, const mopoe_adam* adam, int32_t world, void* stream) {
+    if (!mdl || !tp || !buf || !adam) return fail(MOPOE_ERR_ARG, "null descriptor%s");
+    return launch_adam(*mdl, present_mask, *buf, *adam, world, true, static_cast<hipStream_t>(stream), tp);
+}
+
 int mopoe_profile_enable(int enable) {
     g_prof_on = enable != 0;
     return 0;
@@ -2491,6 +2597,9 @@ int mopoe_sizeof(int which) {
         case 8: return (int)offsetof(mopoe_buffers, status_host);
         case 9: return (int)offsetof(mopoe_model, off_ctrl);
         case 10: return (int)offsetof(mopoe_buffers, wfrag);
+        case 11: return (int)sizeof(mopoe_topology);
+        case 12: return (int)sizeof(mopoe_gbuffers);
+        case 13: return (int)offsetof(mopoe_gbuffers, keep_enc);
         case 7: return (int)offsetof(mopoe_model, num_floats);
         default: return -1;
     }

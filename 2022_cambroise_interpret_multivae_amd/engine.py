@@ -53,6 +53,67 @@ class Workspace:
             self.partials = torch.zeros(groups, self._stride, **self._f)
 
 
+class GeneralWorkspace(Workspace):
+    """The buffers of a general topology (plan.ModelSpec.general: hidden encoder / decoder
+    layers, dropout, the per-subject scale head -- mopoe_gbuffers of the C ABI).  Encoder-
+    side tensors have `eb` row blocks (2 when method poe's unimodal passes re-run the
+    encoder under dropout), decoder-side ones `slots`."""
+
+    def __init__(self, spec, n, slots, device, backward, eb):
+        super().__init__(spec, n, slots, device, backward)
+        f = self._f
+        M, H = spec.num_mods, L.HIDDEN
+        self.eb = eb
+        self.hidden = [None] * M            # (the default topology's single hidden layer)
+        self.heads = [torch.empty(eb * n, spec.heads_dim(m), **f) for m in range(M)]
+        self.partials = torch.zeros((n + L.ROWS - 1) // L.ROWS, self._stride, **f)
+        self.enc_act = [[torch.empty(eb * n, H, **f) for _ in range(spec.enc_layers)]
+                        for _ in range(M)]
+        self.dec_act = [[torch.empty(slots * n, H, **f) for _ in range(spec.dec_layers)]
+                        for _ in range(M)]
+        self.lv = [torch.empty(slots * n, spec.input_dim[m], **f) if spec.sample_scale else None
+                   for m in range(M)]
+        self.enc_pre0 = [None] * M
+        self.g_enc = self.g_dec = [[] for _ in range(M)]
+        self.g_lv = self.g_z = [None] * M
+        if backward:
+            self.g_pre = [None] * M
+            self.g_heads = [torch.empty(eb * n, spec.heads_dim(m), **f) for m in range(M)]
+            self.enc_pre0 = [torch.empty(n, H, **f) if spec.dropout > 0 and spec.enc_layers
+                             else None for _ in range(M)]
+            self.g_enc = [[torch.empty(eb * n, H, **f) for _ in range(spec.enc_layers)]
+                          for _ in range(M)]
+            self.g_dec = [[torch.empty(slots * n, H, **f) for _ in range(spec.dec_layers)]
+                          for _ in range(M)]
+            self.g_lv = [torch.empty(slots * n, spec.input_dim[m], **f) if spec.sample_scale
+                         else None for m in range(M)]
+            self.g_z = [torch.empty(slots * n, spec.ldz(m), **f) for m in range(M)]
+        self._gbuf = None
+
+    def ensure_partials(self, groups):
+        pass        # (the general kernels always cut the batch into groups of 16 rows)
+
+    def gbuffers(self):
+        g = self._gbuf
+        if g is None:
+            g = L.GBuffers()
+            for m in range(len(self.heads)):
+                for l, t in enumerate(self.enc_act[m]):
+                    g.enc_act[m][l] = L.ptr(t)
+                for l, t in enumerate(self.dec_act[m]):
+                    g.dec_act[m][l] = L.ptr(t)
+                for l, t in enumerate(self.g_enc[m]):
+                    g.g_enc[m][l] = L.ptr(t)
+                for l, t in enumerate(self.g_dec[m]):
+                    g.g_dec[m][l] = L.ptr(t)
+                g.enc_pre0[m] = L.ptr(self.enc_pre0[m])
+                g.lv[m] = L.ptr(self.lv[m])
+                g.g_lv[m] = L.ptr(self.g_lv[m])
+                g.g_z[m] = L.ptr(self.g_z[m])
+            self._gbuf = g
+        return g
+
+
 class MoPoEEngine:
     def __init__(self, spec, device="cuda", seed=None):
         if not isinstance(spec, ModelSpec):
@@ -68,7 +129,8 @@ class MoPoEEngine:
         self.exp_avg_sq = torch.zeros(P, **f)
         # fragment-major copies of the head / decoder weights for the four-row form of the
         # fused launch: kept by the library's own updates, rebuilt here after other writers
-        self.wfrag = torch.zeros(L.lib.mopoe_wfrag_floats(spec.c_model), **f)
+        self.wfrag = None if spec.general else \
+            torch.zeros(L.lib.mopoe_wfrag_floats(spec.c_model), **f)
         self._wfrag_version = -1
         self.counters = torch.zeros(L.COUNTERS_ALLOC, dtype=torch.int32, device=self.device)
         # pinned host mirror {steps done, invalid} the last kernel of every training step
@@ -161,21 +223,75 @@ class MoPoEEngine:
         torch.cuda.synchronize(self.device)
 
     # --------------------------------------------------------------- buffers
-    def workspace(self, n, slots, backward, fresh=False):
-        if fresh:
+    def workspace(self, n, slots, backward, fresh=False, eb=1):
+        def make():
+            if self.spec.general:
+                return GeneralWorkspace(self.spec, n, slots, self.device, backward, eb)
             return Workspace(self.spec, n, slots, self.device, backward)
-        key = (n, slots, backward)
+        if fresh:
+            return make()
+        key = (n, slots, backward, eb)
         ws = self._ws.get(key)
         if ws is None:
-            ws = Workspace(self.spec, n, slots, self.device, backward)
-            self._ws[key] = ws
+            ws = self._ws[key] = make()
         return ws
+
+    def _bind_masks(self, plan, ws, masks, train):
+        """Point the step at injected dropout keep masks (0 / 1 floats), given in the order
+        the reference's Dropout modules run (networks.py:19,54): the joint forward's encoder
+        stacks in modality order, its decoder stacks, then -- method poe -- one unimodal
+        forward per batch modality (run_epochs.py:107).  None: the kernels draw them."""
+        spec, g = self.spec, ws.gbuffers()
+        M, n = spec.num_mods, plan.n
+        for m in range(M):
+            for l in range(L.MAX_LAYERS):
+                g.keep_enc[m][l] = None
+                g.keep_dec[m][l] = None
+        if masks is None or not train or spec.dropout == 0.0:
+            return []
+        it = iter(masks)
+        enc = [[[] for _ in range(spec.enc_layers)] for _ in range(M)]
+        dec = [[[] for _ in range(spec.dec_layers)] for _ in range(M)]
+
+        def take(m, stack, layers):
+            for l in range(layers):
+                t = next(it).to(self.device, dtype=torch.float32).contiguous()
+                if tuple(t.shape) != (n, L.HIDDEN):
+                    raise ValueError("keep mask of shape %s, expected %s" % (
+                        tuple(t.shape), (n, L.HIDDEN)))
+                stack[m][l].append(t)
+        for m in plan.present_idx:
+            take(m, enc, spec.enc_layers)
+        for m in plan.present_idx:
+            take(m, dec, spec.dec_layers)
+        for (m, slot, src, pas) in plan.jobs:
+            if src >= 0:            # a unimodal forward of method poe
+                take(m, enc, spec.enc_layers)
+                take(m, dec, spec.dec_layers)
+        if next(it, None) is not None:
+            raise ValueError("more keep masks than Dropout calls in this step")
+        keep = []
+        for m in range(M):
+            for l, parts in enumerate(enc[m]):
+                if parts:
+                    t = torch.cat(parts[:ws.eb]) if len(parts) > 1 else parts[0]
+                    keep.append(t)
+                    g.keep_enc[m][l] = L.ptr(t)
+            for l, parts in enumerate(dec[m]):
+                if parts:
+                    t = torch.cat(parts) if len(parts) > 1 else parts[0]
+                    keep.append(t)
+                    g.keep_dec[m][l] = L.ptr(t)
+        return keep
 
     def refresh_wfrag(self):
         """mopoe_wfrag_refresh: the fragment-major weight copies from `params`.  Runs by
         itself whenever torch has seen a write to the flat buffer or a view of it
         (tensor._version); call it after writes torch does not count (`.data`, raw
         pointers)."""
+        if self.wfrag is None:      # (a general topology: no four-row form, no copies)
+            self._wfrag_version = self.params._version
+            return
         b = L.Buffers()
         b.params = L.ptr(self.params)
         b.wfrag = L.ptr(self.wfrag)
@@ -318,13 +434,20 @@ class MoPoEEngine:
         self._calls += 1
         step.seed = (self.seed + 0x9E3779B97F4A7C15 * self._calls) & (2 ** 64 - 1)
         buf = self._buffers(ws, x, row_index, plan=plan)
-        L.check(L.lib.mopoe_forward(self.spec.c_model, step, buf, L.stream_ptr()),
-                "mopoe_forward")
+        if self.spec.general:       # (evaluation: the Dropout modules are the identity)
+            self._bind_masks(plan, ws, None, False)
+            L.check(L.lib.mopoe_general_forward(self.spec.c_model, self.spec.c_topo, step, buf,
+                                                ws.gbuffers(), L.stream_ptr()),
+                    "mopoe_general_forward")
+        else:
+            L.check(L.lib.mopoe_forward(self.spec.c_model, step, buf, L.stream_ptr()),
+                    "mopoe_forward")
         self._keep = (x, keep, row_index)
         return plan, ws
 
     def train_step(self, batch, eps=None, row_index=None, apply_adam=True,
-                   stats_host=None, comm=None, loss_scale=1.0, rccl=None, check=True):
+                   stats_host=None, comm=None, loss_scale=1.0, rccl=None, check=True,
+                   masks=None):
         """mopoe_train_step: forward + backward (+ fused Adam).  `stats_host`:
         a pinned host tensor the kernel writes the step's scalars into (the
         per-step log without a copy on the stream; read it after a sync or a
@@ -334,20 +457,31 @@ class MoPoEEngine:
         `rccl` (an RcclComm): mopoe_rccl_train_step -- backward, RCCL all-reduce of the
         gradient buffer and Adam with the mean, enqueued by this one call.
         `loss_scale`: weight of the batch's loss terms (parallel.py).
-        `check=False`: the caller looks after invalid steps itself (parallel.StepRetry)."""
+        `check=False`: the caller looks after invalid steps itself (parallel.StepRetry).
+        `masks`: injected dropout keep masks of a general topology (_bind_masks)."""
         if check:
             self.check_valid()      # (pinned host mirror: no synchronisation)
         x, n, row_index = self._prepare(batch, row_index)
         plan = self.spec.plan(list(x.keys()), n, True, None, True, True,
                               loss_scale=loss_scale)
         slots = max(plan.jobs_per_mod)
-        ws = self.workspace(n, slots, True)
         step = plan.c_step
+        eb = L.lib.mopoe_general_enc_blocks(self.spec.c_topo, step, 1) if self.spec.general else 1
+        ws = self.workspace(n, slots, True, eb=eb)
         keep = self._bind_noise(plan, step, eps)
         step.seed = self.seed
         buf = self._buffers(ws, x, row_index, stats_host, plan=plan)
         adam = C.byref(self.adam) if apply_adam else None
-        if comm is not None or rccl is not None:
+        if self.spec.general:
+            if comm is not None:
+                raise NotImplementedError("the peer-window exchange forms serve the default "
+                                          "topology; a general one exchanges over RCCL")
+            keep = keep + self._bind_masks(plan, ws, masks, True)
+            L.check(L.lib.mopoe_general_train_step(
+                self.spec.c_model, self.spec.c_topo, step, buf, ws.gbuffers(), adam,
+                rccl._c if rccl is not None else None, L.stream_ptr()),
+                "mopoe_general_train_step")
+        elif comm is not None or rccl is not None:
             if not apply_adam or (comm is not None and rccl is not None):
                 raise ValueError("the exchanging step applies Adam (through ONE communicator)")
             if rccl is not None:
@@ -374,6 +508,12 @@ class MoPoEEngine:
         if present_mask is None:
             present_mask = self.last_present_mask
         b = self._optim_buffers(L.Buffers())
+        if self.spec.general:
+            L.check(L.lib.mopoe_general_adam_step(self.spec.c_model, self.spec.c_topo,
+                                                  present_mask, b, C.byref(self.adam),
+                                                  int(world), L.stream_ptr()),
+                    "mopoe_general_adam_step")
+            return
         L.check(L.lib.mopoe_adam_step(self.spec.c_model, present_mask, b,
                                       C.byref(self.adam), int(world), L.stream_ptr()),
                 "mopoe_adam_step")
@@ -391,8 +531,15 @@ class MoPoEEngine:
             if self.spec.has_style(m):
                 z = torch.cat((styles[name].to(content.device), content), dim=1)
             k = "decoders.%s." % name
+            for l in range(self.spec.dec_layers):    # (evaluation: Dropout is the identity)
+                z = ops.linear(z, self.views[k + "shared_decoder.%d.weight" % (3 * l)],
+                               self.views[k + "shared_decoder.%d.bias" % (3 * l)], relu=True)
             loc = ops.linear(z, self.views[k + "out_mu.weight"], self.views[k + "out_mu.bias"])
-            out[name] = (loc, (self.views[k + "logvar"] * 0.5).exp())
+            if self.spec.sample_scale:
+                logvar = ops.linear(z, self.views[k + "logvar.weight"], self.views[k + "logvar.bias"])
+            else:
+                logvar = self.views[k + "logvar"]
+            out[name] = (loc, (logvar * 0.5).exp())
         return out
 
     # --------------------------------------------------------------- results
@@ -405,7 +552,7 @@ class MoPoEEngine:
         for m, name in enumerate(spec.names):
             s = spec.style_dim[m]
             if name in plan.present:
-                h = ws.heads[m]
+                h = ws.heads[m][:n]     # (a general topology's second row block: not the API's)
                 enc_mods[name + "_style"] = [h[:, 0:s], h[:, s:2 * s]] \
                     if spec.has_style(m) else [None, None]
                 enc_mods[name] = [h[:, 2 * s:2 * s + D], h[:, 2 * s + D:2 * s + 2 * D]]
@@ -443,7 +590,8 @@ class MoPoEEngine:
         rec = OrderedDict()
         for m, name in enumerate(spec.names):
             if name in plan.present:
-                scale = (self.views["decoders.%s.logvar" % name] * 0.5).exp()
+                scale = (ws.lv[m][:n] * 0.5).exp() if spec.sample_scale else \
+                    (self.views["decoders.%s.logvar" % name] * 0.5).exp()
                 lik = torch.distributions.Laplace if spec.likelihood == "laplace" \
                     else torch.distributions.Normal      # (modalities/modality.py:18-30)
                 rec[name] = lik(ws.loc[m][:n], scale, validate_args=False)

@@ -11,15 +11,28 @@ from ... import ops
 HIDDEN = 256
 
 
-def _check_topology(flags):
-    if flags.num_hidden_layer_encoder != 1 or flags.num_hidden_layer_decoder != 0:
-        raise NotImplementedError(
-            "the HIP path implements the train_exp default topology: one hidden "
-            "encoder layer, no hidden decoder layer (reference workflow.py:41-49)")
-    if getattr(flags, "learn_output_sample_scale", False):
-        raise NotImplementedError("learn_output_sample_scale")
-    if getattr(flags, "dropout_rate", 0.0) != 0.0:
-        raise NotImplementedError("dropout_rate != 0")
+def _stack(input_dim, layers, dropout_rate):
+    """`layers` x (Linear(., 256), ReLU, Dropout): the Linear of layer l is module 3 l
+    (reference networks.py:16-20,51-55; the state_dict keys hang on these indices)."""
+    seq = nn.Sequential()
+    for _ in range(layers):
+        seq.append(nn.Linear(input_dim, HIDDEN))
+        seq.append(nn.ReLU())
+        seq.append(nn.Dropout(dropout_rate))
+        input_dim = HIDDEN
+    return seq, input_dim
+
+
+def _run_stack(seq, h, training):
+    """Standalone forward of a stack on the HIP linear kernel.  Outside the fused /
+    general training step (whose kernels draw or take the masks themselves) a live
+    Dropout is torch's own."""
+    for mod in seq:
+        if isinstance(mod, nn.Linear):
+            h = ops.linear(h, mod.weight, mod.bias, relu=True)
+        elif isinstance(mod, nn.Dropout) and training and mod.p > 0:
+            h = torch.nn.functional.dropout(h, mod.p, True)
+    return h
 
 
 class Encoder(nn.Module):
@@ -27,21 +40,18 @@ class Encoder(nn.Module):
 
     def __init__(self, flags, mod_num):
         super().__init__()
-        _check_topology(flags)
         self.flags = flags
-        self.shared_encoder = nn.Sequential(
-            nn.Linear(flags.input_dim[mod_num], HIDDEN), nn.ReLU(),
-            nn.Dropout(flags.dropout_rate))
+        self.shared_encoder, width = _stack(flags.input_dim[mod_num],
+                                            flags.num_hidden_layer_encoder, flags.dropout_rate)
         self.style_dim = flags.style_dim[mod_num]
-        self.class_mu = nn.Linear(HIDDEN, flags.class_dim)
-        self.class_logvar = nn.Linear(HIDDEN, flags.class_dim)
+        self.class_mu = nn.Linear(width, flags.class_dim)
+        self.class_logvar = nn.Linear(width, flags.class_dim)
         if flags.factorized_representation and self.style_dim > 0:
-            self.style_mu = nn.Linear(HIDDEN, self.style_dim)
-            self.style_logvar = nn.Linear(HIDDEN, self.style_dim)
+            self.style_mu = nn.Linear(width, self.style_dim)
+            self.style_logvar = nn.Linear(width, self.style_dim)
 
     def forward(self, h):
-        lin = self.shared_encoder[0]
-        h = ops.linear(h, lin.weight, lin.bias, relu=True)
+        h = _run_stack(self.shared_encoder, h, self.training)
         c_mu = ops.linear(h, self.class_mu.weight, self.class_mu.bias)
         c_lv = ops.linear(h, self.class_logvar.weight, self.class_logvar.bias)
         if self.flags.factorized_representation and self.style_dim > 0:
@@ -56,21 +66,28 @@ class Decoder(nn.Module):
 
     def __init__(self, flags, mod_num):
         super().__init__()
-        _check_topology(flags)
         self.flags = flags
-        self.shared_decoder = nn.Sequential()
         self.style_dim = flags.style_dim[mod_num]
-        self.out_mu = nn.Linear(self.style_dim + flags.class_dim,
-                                flags.input_dim[mod_num])
-        self.logvar = nn.Parameter(
-            data=torch.FloatTensor(1, flags.input_dim[mod_num]).fill_(
-                flags.initial_out_logvar),
-            requires_grad=flags.learn_output_scale)
+        self.shared_decoder, width = _stack(self.style_dim + flags.class_dim,
+                                            flags.num_hidden_layer_decoder, flags.dropout_rate)
+        self.out_mu = nn.Linear(width, flags.input_dim[mod_num])
+        if getattr(flags, "learn_output_sample_scale", False):
+            self.logvar = nn.Linear(width, flags.input_dim[mod_num])
+        else:
+            self.logvar = nn.Parameter(
+                data=torch.FloatTensor(1, flags.input_dim[mod_num]).fill_(
+                    flags.initial_out_logvar),
+                requires_grad=flags.learn_output_scale)
 
     def forward(self, style_latent_space, class_latent_space):
         if self.flags.factorized_representation and self.style_dim > 0:
             z = torch.cat((style_latent_space, class_latent_space), dim=1)
         else:
             z = class_latent_space
-        x_hat = ops.linear(z, self.out_mu.weight, self.out_mu.bias)
-        return x_hat, (self.logvar.detach() * 0.5).exp().to(z.device)
+        h = _run_stack(self.shared_decoder, z, self.training)
+        x_hat = ops.linear(h, self.out_mu.weight, self.out_mu.bias)
+        if getattr(self.flags, "learn_output_sample_scale", False):
+            logvar = ops.linear(h, self.logvar.weight, self.logvar.bias)
+        else:
+            logvar = self.logvar.detach()
+        return x_hat, (logvar * 0.5).exp().to(z.device)

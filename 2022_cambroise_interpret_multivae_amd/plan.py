@@ -30,7 +30,8 @@ class ModelSpec:
                  beta_style=1.0, beta_content=1.0, initial_out_logvar=-3.0,
                  learn_output_scale=True, lr=0.002, betas=(0.9, 0.999),
                  adam_eps=1e-8, rec_weights=None, poe_unimodal_elbos=True,
-                 likelihood="normal"):
+                 likelihood="normal", enc_layers=1, dec_layers=0, dropout=0.0,
+                 sample_scale=False):
         if method not in METHODS:
             raise NotImplementedError(
                 "method %r: only joint_elbo / poe / moe are on the MI355X hot "
@@ -78,6 +79,21 @@ class ModelSpec:
             self.subsets["_".join(sorted(mod_names))] = sorted(mod_names)
         self.subset_keys = list(self.subsets.keys())
 
+        # workflow.py:41-49: num_hidden_layer_encoder / num_hidden_layer_decoder /
+        # dropout_rate / out_scale_per_subject (-> flags.learn_output_sample_scale, :112) --
+        # networks.py:16-20,51-59.  The defaults are the fused two-launch step; any other
+        # topology runs the general chain of launches (csrc/mopoe_general.inc)
+        self.enc_layers = int(enc_layers)
+        self.dec_layers = int(dec_layers)
+        self.dropout = float(dropout)
+        self.sample_scale = bool(sample_scale)
+        if not (0 <= self.enc_layers <= L.MAX_LAYERS and 0 <= self.dec_layers <= L.MAX_LAYERS):
+            raise ValueError("0..%d hidden layers per encoder / decoder" % L.MAX_LAYERS)
+        if not 0.0 <= self.dropout < 1.0:
+            raise ValueError("dropout_rate must be in [0, 1)")
+        self.general = (self.enc_layers, self.dec_layers, self.dropout,
+                        self.sample_scale) != (1, 0, 0.0, False)
+
         c = L.Model()
         c.num_mods = M
         c.class_dim = self.class_dim
@@ -85,8 +101,13 @@ class ModelSpec:
             c.input_dim[m] = self.input_dim[m]
             c.style_dim[m] = self.style_dim[m]
         c.learn_output_scale = int(self.learn_output_scale)
-        L.check(L.lib.mopoe_model_layout(c), "mopoe_model_layout")
+        t = L.Topology()
+        t.enc_layers, t.dec_layers = self.enc_layers, self.dec_layers
+        t.dropout, t.sample_scale = self.dropout, int(self.sample_scale)
+        # (the default topology's offsets are mopoe_model_layout's)
+        L.check(L.lib.mopoe_topology_layout(c, t), "mopoe_topology_layout")
         self.c_model = c
+        self.c_topo = t
         self.num_floats = c.num_floats
         self._plans = {}
 
@@ -95,15 +116,6 @@ class ModelSpec:
         """Build from the SimpleNamespace workflow.train_exp assembles."""
         if getattr(flags, "modality_jsd", False):
             raise NotImplementedError("method jsd is outside the hot path")
-        if getattr(flags, "num_hidden_layer_encoder", 1) != 1 or \
-                getattr(flags, "num_hidden_layer_decoder", 0) != 0:
-            raise NotImplementedError(
-                "the HIP path implements the train_exp default topology: one "
-                "hidden encoder layer, no hidden decoder layer")
-        if getattr(flags, "learn_output_sample_scale", False):
-            raise NotImplementedError("learn_output_sample_scale")
-        if getattr(flags, "dropout_rate", 0.0) != 0.0:
-            raise NotImplementedError("dropout_rate != 0")
         method = ("poe" if flags.modality_poe else
                   "moe" if flags.modality_moe else "joint_elbo")
         return cls(names, flags.input_dim, flags.style_dim,
@@ -117,7 +129,11 @@ class ModelSpec:
                    betas=(getattr(flags, "beta_1", 0.9),
                           getattr(flags, "beta_2", 0.999)),
                    poe_unimodal_elbos=getattr(flags, "poe_unimodal_elbos", True),
-                   likelihood=getattr(flags, "likelihood", "normal"))
+                   likelihood=getattr(flags, "likelihood", "normal"),
+                   enc_layers=getattr(flags, "num_hidden_layer_encoder", 1),
+                   dec_layers=getattr(flags, "num_hidden_layer_decoder", 0),
+                   dropout=getattr(flags, "dropout_rate", 0.0),
+                   sample_scale=getattr(flags, "learn_output_sample_scale", False))
 
     @property
     def num_mods(self):
@@ -135,22 +151,32 @@ class ModelSpec:
     def ldz(self, m):
         return (self.z_dim(m) + 3) // 4 * 4
 
+    def enc_width(self, m):
+        """columns of what the encoder heads read"""
+        return L.HIDDEN if self.enc_layers > 0 else self.input_dim[m]
+
+    def dec_width(self, m):
+        """columns of what out_mu (and the logvar head) read"""
+        return L.HIDDEN if self.dec_layers > 0 else self.z_dim(m)
+
     # ------------------------------------------------------------------
     def param_views(self, flat):
         """name (reference state_dict key) -> view into the flat buffer."""
-        c = self.c_model
+        c, t = self.c_model, self.c_topo
         D, H = self.class_dim, L.HIDDEN
         out = OrderedDict()
         for m, name in enumerate(self.names):
             d, s = self.input_dim[m], self.style_dim[m]
             e = "encoders.%s." % name
-            out[e + "shared_encoder.0.weight"] = \
-                flat[c.off_w1[m]:c.off_w1[m] + H * d].view(H, d)
-            out[e + "shared_encoder.0.bias"] = flat[c.off_b1[m]:c.off_b1[m] + H]
+            for l in range(self.enc_layers):   # nn.Sequential of (Linear, ReLU, Dropout)
+                k, w0, b0 = (d if l == 0 else H), t.off_we[m][l], t.off_be[m][l]
+                out[e + "shared_encoder.%d.weight" % (3 * l)] = flat[w0:w0 + H * k].view(H, k)
+                out[e + "shared_encoder.%d.bias" % (3 * l)] = flat[b0:b0 + H]
             wh, bh = c.off_wh[m], c.off_bh[m]
+            ew = self.enc_width(m)
 
-            def rows(r0, n):
-                return flat[wh + r0 * H:wh + (r0 + n) * H].view(n, H)
+            def rows(r0, n, wh=wh, ew=ew):
+                return flat[wh + r0 * ew:wh + (r0 + n) * ew].view(n, ew)
 
             out[e + "class_mu.weight"] = rows(2 * s, D)
             out[e + "class_mu.bias"] = flat[bh + 2 * s:bh + 2 * s + D]
@@ -162,12 +188,20 @@ class ModelSpec:
                 out[e + "style_logvar.weight"] = rows(s, s)
                 out[e + "style_logvar.bias"] = flat[bh + s:bh + 2 * s]
         for m, name in enumerate(self.names):
-            d, zd = self.input_dim[m], self.z_dim(m)
+            d, zd, dw = self.input_dim[m], self.z_dim(m), self.dec_width(m)
             k = "decoders.%s." % name
-            out[k + "logvar"] = flat[c.off_lvo[m]:c.off_lvo[m] + d].view(1, d)
+            if not self.sample_scale:
+                out[k + "logvar"] = flat[c.off_lvo[m]:c.off_lvo[m] + d].view(1, d)
+            for l in range(self.dec_layers):
+                kk, w0, b0 = (zd if l == 0 else H), t.off_wg[m][l], t.off_bg[m][l]
+                out[k + "shared_decoder.%d.weight" % (3 * l)] = flat[w0:w0 + H * kk].view(H, kk)
+                out[k + "shared_decoder.%d.bias" % (3 * l)] = flat[b0:b0 + H]
             out[k + "out_mu.weight"] = \
-                flat[c.off_wd[m]:c.off_wd[m] + d * zd].view(d, zd)
+                flat[c.off_wd[m]:c.off_wd[m] + d * dw].view(d, dw)
             out[k + "out_mu.bias"] = flat[c.off_bd[m]:c.off_bd[m] + d]
+            if self.sample_scale:     # networks.py:58-59: a Linear head instead of the parameter
+                out[k + "logvar.weight"] = flat[t.off_wlv[m]:t.off_wlv[m] + d * dw].view(d, dw)
+                out[k + "logvar.bias"] = flat[t.off_blv[m]:t.off_blv[m] + d]
         return out
 
     # ------------------------------------------------------------------

@@ -37,6 +37,7 @@ extern "C" {
 #define MOPOE_IPC_HANDLE_BYTES 64
 #define MOPOE_RCCL_ID_BYTES 128 /* ncclUniqueId                                  */
 #define MOPOE_ROWS 16         /* batch rows per MFMA tile; a row group has <= 16 */
+#define MOPOE_MAX_LAYERS 4    /* hidden layers of an encoder / a decoder (general topology) */
 
 #define MOPOE_ERR_ARG (-1)
 #define MOPOE_ERR_HIP (-2)
@@ -294,7 +295,8 @@ const char* mopoe_last_error(void);
 /* sizeof / offsetof probes so a binding can verify its struct mirrors:
  * 0 mopoe_model, 1 mopoe_step, 2 mopoe_buffers, 3 mopoe_adam (sizes);
  * 4 step.job_eps_content, 5 step.comp_w, 6 buffers.partials,
- * 7 model.num_floats (offsets); -1 otherwise. */
+ * 7 model.num_floats, 8 buffers.status_host, 9 model.off_ctrl, 10 buffers.wfrag (offsets);
+ * 11 mopoe_topology, 12 mopoe_gbuffers (sizes), 13 gbuffers.keep_enc (offset); -1 otherwise. */
 int mopoe_sizeof(int which);
 
 /* leading dimension (floats) of z[m]: round_up(zd_m, 4) */
@@ -400,6 +402,83 @@ int mopoe_comm_train_step(mopoe_comm* comm, const mopoe_model* model,
                           const mopoe_adam* adam, void* stream);
 int mopoe_comm_status(mopoe_comm* comm, int32_t* timeouts);
 int mopoe_comm_destroy(mopoe_comm* comm);
+
+/* ---------------------------------------------------------------------------
+ * General topologies (ABI 9): the flags of workflow.train_exp beyond its defaults
+ * (workflow.py:41-49 -> multimodal_cohort/networks/networks.py:16-20,51-59,66-77):
+ *   enc_layers    num_hidden_layer_encoder: Linear(., 256) + ReLU + Dropout, 0..4 of them
+ *                 (0: the heads read x directly)
+ *   dec_layers    num_hidden_layer_decoder: the same stack between z and out_mu
+ *   dropout       dropout_rate of every Dropout module (live in training steps only;
+ *                 ATen's arithmetic x * (keep / (1 - p)))
+ *   sample_scale  learn_output_sample_scale: decoders.<m>.logvar is a Linear head on the
+ *                 decoder's last hidden layer (a (N, d_m) scale) instead of a parameter
+ * The default topology {1, 0, 0, 0} is what mopoe_forward / mopoe_train_step implement (one
+ * fused launch + the weight-gradient launch); every other one runs through the entry points
+ * below as a chain of launches around the same kernels (csrc/mopoe_general.inc).
+ *
+ * mopoe_topology_layout fills the offsets of BOTH structs: per modality the encoder's
+ * parameters in one run of the flat buffer -- hidden layers (shared_encoder.<3l>), then the
+ * heads rows [style_mu | style_logvar | class_mu | class_logvar] of width 256 (or d_m) --
+ * and the decoder's in another: hidden layers (shared_decoder.<3l>), out_mu (d_m, 256 or
+ * zd_m), then logvar (1, d_m) or the head logvar.weight / logvar.bias.
+ * ------------------------------------------------------------------------- */
+typedef struct mopoe_topology {
+    int32_t enc_layers, dec_layers;
+    float dropout;
+    int32_t sample_scale;
+    /* filled by mopoe_topology_layout(): float offsets into the flat buffer */
+    int32_t off_we[MOPOE_MAX_MODS][MOPOE_MAX_LAYERS];  /* encoder layer l weight (256, l ? 256 : d_m) */
+    int32_t off_be[MOPOE_MAX_MODS][MOPOE_MAX_LAYERS];
+    int32_t off_wg[MOPOE_MAX_MODS][MOPOE_MAX_LAYERS];  /* decoder layer l weight (256, l ? 256 : zd_m) */
+    int32_t off_bg[MOPOE_MAX_MODS][MOPOE_MAX_LAYERS];
+    int32_t off_wlv[MOPOE_MAX_MODS];                   /* logvar head (d_m, 256 or zd_m)             */
+    int32_t off_blv[MOPOE_MAX_MODS];
+} mopoe_topology;
+
+int mopoe_topology_layout(mopoe_model* model, mopoe_topology* topo);
+
+/* Buffers of a general topology, next to mopoe_buffers (whose `hidden`, `g_pre` and `wfrag`
+ * it does not use).  Caller-owned, row-major float32.  EB = mopoe_general_enc_blocks():
+ * encoder-side tensors (these, and heads / g_heads of mopoe_buffers) have EB * n rows -- 2
+ * when a training step with dropout has decoder jobs fed by a subset of their own (method
+ * poe's unimodal ELBOs re-run the model, run_epochs.py:104-128: with live Dropout modules
+ * the second encoder pass draws new masks; its rows are the second row block).  Decoder-side
+ * tensors have R_m rows like z / loc. */
+typedef struct mopoe_gbuffers {
+    float* enc_act[MOPOE_MAX_MODS][MOPOE_MAX_LAYERS];  /* (EB n, 256) output of encoder layer l   */
+    float* enc_pre0[MOPOE_MAX_MODS];                   /* (n, 256) layer 0 before its Dropout
+                                                          (training with dropout > 0 only)       */
+    float* dec_act[MOPOE_MAX_MODS][MOPOE_MAX_LAYERS];  /* (R_m, 256) output of decoder layer l    */
+    float* g_enc[MOPOE_MAX_MODS][MOPOE_MAX_LAYERS];    /* (EB n, 256) d loss / d pre-activation   */
+    float* g_dec[MOPOE_MAX_MODS][MOPOE_MAX_LAYERS];    /* (R_m, 256)                              */
+    float* lv[MOPOE_MAX_MODS];                         /* (R_m, d_m) per-sample logvar (sample_scale) */
+    float* g_lv[MOPOE_MAX_MODS];                       /* its gradient                             */
+    float* g_z[MOPOE_MAX_MODS];                        /* (R_m, ldz_m) d loss / d z                */
+    /* injected dropout keep masks (0 / 1 floats, the shape of the activation) or NULL: the
+     * kernels draw them (Philox, keyed by seed / step / layer / element) */
+    const float* keep_enc[MOPOE_MAX_MODS][MOPOE_MAX_LAYERS];
+    const float* keep_dec[MOPOE_MAX_MODS][MOPOE_MAX_LAYERS];
+} mopoe_gbuffers;
+
+/* row blocks of the encoder-side buffers for this step: 1 or 2 (see mopoe_gbuffers) */
+int mopoe_general_enc_blocks(const mopoe_topology* topo, const mopoe_step* step, int train);
+/* mopoe_forward for a general topology (evaluation: Dropout is the identity) */
+int mopoe_general_forward(const mopoe_model* model, const mopoe_topology* topo,
+                          const mopoe_step* step, const mopoe_buffers* buf,
+                          const mopoe_gbuffers* gbuf, void* stream);
+/* mopoe_train_step for a general topology.  `rccl` NULL: the one-rank step (Adam fused
+ * into the weight-gradient launches when `adam` is given).  `rccl` non-NULL: the N-rank step
+ * as in mopoe_rccl_train_step (gradients, ncclAllReduce, the Adam launch). */
+struct mopoe_rccl;
+int mopoe_general_train_step(const mopoe_model* model, const mopoe_topology* topo,
+                             const mopoe_step* step, const mopoe_buffers* buf,
+                             const mopoe_gbuffers* gbuf, const mopoe_adam* adam,
+                             struct mopoe_rccl* rccl, void* stream);
+/* mopoe_adam_step over the segments of a general topology */
+int mopoe_general_adam_step(const mopoe_model* model, const mopoe_topology* topo,
+                            int32_t present_mask, const mopoe_buffers* buf,
+                            const mopoe_adam* adam, int32_t world, void* stream);
 
 /* ---------------------------------------------------------------------------
  * The data-parallel step over RCCL as ONE call (ABI 9; SURVEY.md section 8e: "one

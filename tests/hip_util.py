@@ -65,7 +65,9 @@ def make_engine(cfg, device="cuda"):
                         learn_output_scale=cfg.learn_output_scale, lr=cfg.lr,
                         betas=cfg.betas, adam_eps=cfg.adam_eps,
                         poe_unimodal_elbos=cfg.poe_unimodal_elbos,
-                        likelihood=cfg.likelihood)
+                        likelihood=cfg.likelihood, enc_layers=cfg.enc_layers,
+                        dec_layers=cfg.dec_layers, dropout=cfg.dropout,
+                        sample_scale=cfg.sample_scale)
     eng = mm.MoPoEEngine(spec, device)
     eng.load_params(mo.init_params(cfg, 0))
     return spec, eng
