@@ -130,11 +130,13 @@ class DataParallelStep:
             self.synchronise_replicas()
 
     def __call__(self, batch, eps=None, row_index=None, loss_scale=1.0, stats_host=None,
-                 check=True):
+                 check=True, masks=None):
         eng = self.engine
         kw = dict(eps=eps, row_index=row_index, loss_scale=loss_scale, stats_host=stats_host)
         if hasattr(eng, "invalid_since"):
             kw["check"] = check
+        if masks is not None:       # injected dropout keep masks (a general topology)
+            kw["masks"] = masks
         if world_size() == 1 and self.rccl is None:
             return eng.train_step(batch, apply_adam=True, **kw)
         if self.exchange == "rccl":

@@ -28,11 +28,11 @@ def make_flags(cfg, device):
         factorized_representation=cfg.factorized, input_dim=list(cfg.input_dim),
         joint_elbo=cfg.method == "joint_elbo", modality_jsd=False,
         modality_moe=cfg.method == "moe", modality_poe=cfg.method == "poe",
-        poe_unimodal_elbos=True, num_hidden_layer_encoder=1,
-        num_hidden_layer_decoder=0, dropout_rate=0.0,
+        poe_unimodal_elbos=True, num_hidden_layer_encoder=cfg.enc_layers,
+        num_hidden_layer_decoder=cfg.dec_layers, dropout_rate=cfg.dropout,
         initial_out_logvar=cfg.initial_out_logvar,
-        learn_output_scale=cfg.learn_output_scale, learn_output_sample_scale=False,
-        likelihood="normal", style_dim=list(cfg.style_dim), num_models=1, num_mods=M,
+        learn_output_scale=cfg.learn_output_scale,
+        learn_output_sample_scale=cfg.sample_scale, likelihood="normal", style_dim=list(cfg.style_dim), num_models=1, num_mods=M,
         device=torch.device(device), alpha_modalities=[1.0 / (M + 1)] * (M + 1),
         grad_scaling=False, initial_learning_rate=cfg.lr, beta_1=cfg.betas[0],
         beta_2=cfg.betas[1], start_epoch=0, end_epoch=1, dir_checkpoints="/tmp",

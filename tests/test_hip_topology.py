@@ -1,0 +1,166 @@
+"""GPU: the topologies workflow.train_exp exposes beyond its defaults (hidden encoder /
+decoder layers, dropout, the per-subject output scale head; reference networks.py:16-20,
+51-59,66-77) on the HIP path's general chain of launches (csrc/mopoe_general.inc).
+
+The training steps of every `t_*` fixture recorded from the reference run in
+test_hip_parity.py (oracle's eps and dropout keep masks injected).  Here: evaluation
+forwards (Dropout = identity) with the flags of BaseMMVae.forward, the device-drawn masks,
+the mirror modules' surface, the zero_grad / backward / step sequence, the N-rank step."""
+from collections import OrderedDict
+from importlib import import_module
+
+import pytest
+import torch
+
+import mopoe_amd as mm
+import mopoe_oracle as mo
+from hip_util import Report, TOL, compare_forward, make_engine
+from surface_util import make_experiment, run_epochs
+
+pytestmark = pytest.mark.gpu
+L = mm._lib
+C1 = dict(names=["clinical", "rois"], input_dim=[7, 444], style_dim=[3, 20])
+C5 = dict(names=["clinical", "rois", "snps", "tracts"], input_dim=[7, 444, 128, 64], style_dim=[3, 3, 3, 3])
+TOPOS = [
+    dict(enc_layers=2, dec_layers=1),
+    dict(enc_layers=0, dec_layers=0, sample_scale=True),
+    dict(enc_layers=3, dec_layers=2, dropout=0.3, sample_scale=True),
+    dict(enc_layers=1, dec_layers=0, dropout=0.1),
+]
+
+
+@pytest.mark.parametrize("topo", TOPOS, ids=lambda t: "-".join("%s%s" % (k[:3], v) for k, v in t.items()))
+@pytest.mark.parametrize("method,base", [("joint_elbo", C1), ("poe", C1), ("moe", C1), ("joint_elbo", C5)])
+def test_evaluation_forwards_match_oracle(topo, method, base):
+    cfg = mo.Config(method=method, **base, **topo)
+    spec, eng = make_engine(cfg)
+    assert spec.general
+    params = mo.init_params(cfg, 0)
+    present = cfg.names if base is C1 else ["rois", "snps", "tracts"]
+    rep = Report("fwd %s %s" % (method, topo))
+    for n, sample, expert in ((37, True, None), (16, False, None), (21, True, "_".join(sorted(present))),
+                              (2304, False, None)):
+        x = mo.make_inputs(cfg.names, cfg.input_dim, n, seed=n, present=present)
+        noise = mo.Noise(generator=mo.noise_rng(n))
+        with torch.no_grad():
+            out = mo.forward(params, cfg, x, noise, sample_latents=sample, use_expert=expert)
+        plan, ws = eng.forward(x, sample=sample, use_expert=expert, eps=noise.tape)
+        torch.cuda.synchronize()
+        compare_forward(rep, spec, eng, plan, ws, out, prefix="n%d/" % n)
+    rep.finish()
+
+
+def test_device_drawn_dropout_masks():
+    """Without injected masks the kernels draw them (Philox, keyed by seed / step / layer /
+    element): a unit is kept with probability 1 - p and scaled by 1 / (1 - p); the same step
+    of a twin engine draws the same masks, the next step different ones."""
+    cfg = mo.Config(**C1, enc_layers=2, dec_layers=1, dropout=0.25)
+    _, a = make_engine(cfg)
+    _, b = make_engine(cfg)
+    x = mo.make_inputs(cfg.names, cfg.input_dim, 512, seed=1)
+    eps = mo.Noise(generator=mo.noise_rng(2))
+    mo.forward(mo.init_params(cfg, 0), cfg, x, eps, train=False)
+    kept = []
+    for step in range(2):
+        (_, wa), (_, wb) = a.train_step(x, eps=eps.tape), b.train_step(x, eps=eps.tape)
+        torch.cuda.synchronize()
+        for m in range(2):
+            pre, act = wa.enc_pre0[m], wa.enc_act[m][0]
+            live = pre > 0
+            keep = (act != 0)[live].float().mean().item()
+            assert abs(keep - 0.75) < 0.01, keep
+            on = live & (act != 0)
+            assert torch.allclose(act[on], pre[on] * (1.0 / 0.75), rtol=1e-6)
+            assert not (act[~live] != 0).any()
+            assert torch.equal(wa.enc_act[m][1], wb.enc_act[m][1])     # twin: the same masks
+            kept.append((act != 0).clone())
+        assert torch.equal(a.params, b.params)
+    assert not torch.equal(kept[0], kept[2])        # another step, other masks
+    a.check_valid(sync=True)
+    loss = float(wa.stats[L.STAT_TOTAL_LOSS])
+    assert loss == loss and abs(loss) < 1e7
+
+
+@pytest.mark.parametrize("method", ["joint_elbo", "poe"])
+def test_mirror_modules_and_the_train_sequence(method):
+    """The mirror Encoder / Decoder carry the reference's state_dict keys for a general
+    topology; zero_grad / backward / step (run_epochs.py:180-182) in evaluation-free
+    training mode with dropout 0 equals the oracle."""
+    cfg = mo.Config(**C1, method=method, enc_layers=2, dec_layers=2, sample_scale=True)
+    exp = make_experiment(cfg, "cuda")
+    model = exp.models
+    assert list(model.state_dict().keys()) == list(mo.param_shapes(cfg).keys())
+    params = mo.init_params(cfg, 0)
+    model.load_state_dict(params)
+    state = mo.adam_init(params)
+    x = mo.make_inputs(cfg.names, cfg.input_dim, 48, seed=50)
+    # standalone module forwards (mopoe_linear per layer)
+    rep = Report("topology surface " + method)
+    model.eval()
+    for m, name in enumerate(cfg.names):
+        got = model.encoders[name](x[name].cuda())
+        want = mo.encoder_forward(params, cfg, m, x[name])[:4]
+        for g, w, nm in zip(got, want, ("s_mu", "s_lv", "c_mu", "c_lv")):
+            rep.close("%s/%s" % (name, nm), g, w, *TOL["latent"])
+        zs, zc = torch.randn(48, cfg.style_dim[m]), torch.randn(48, cfg.class_dim)
+        loc, scale = model.decoders[name](zs.cuda(), zc.cuda())
+        wloc, wscale = mo.decoder_forward(params, cfg, m, zs, zc)
+        rep.close(name + "/loc", loc, wloc, *TOL["loc"])
+        rep.close(name + "/scale", scale, wscale, 2e-5, 1e-6)
+    gen = model.generate(16)
+    assert gen["rois"].shape == (16, 444)
+    model.train()
+    noise = mo.Noise(generator=mo.noise_rng(70))
+    out, grads = mo.loss_and_grads(params, cfg, x, noise)
+    eng = model.engine
+    orig = eng.train_step
+    eng.train_step = lambda b, eps=None, **kw: orig(b, eps=noise.tape, **kw)
+    batch = (OrderedDict((k, v.double()) for k, v in x.items()), None, {})
+    res = run_epochs.basic_routine_epoch(exp, 0, batch)
+    eng.train_step = orig
+    exp.optimizers.zero_grad()
+    res["total_loss"].backward()
+    rep.close("total_loss", res["total_loss"], out["total_loss"], *TOL["scalar"])
+    named = dict(model.named_parameters())
+    for k, g in grads.items():
+        assert named[k].grad is not None, k
+        rep.close_scaled("grad/" + k, named[k].grad, g, TOL["grad"])
+    exp.optimizers.step()
+    mo.adam_step(cfg, params, grads, state)
+    torch.cuda.synchronize()
+    for k, g in grads.items():
+        mask = g.abs() > 1e-6
+        rep.close("param/" + k, named[k].detach().cpu()[mask], params[k][mask], *TOL["param1"])
+    rep.finish()
+
+
+def test_one_call_rccl_step_of_a_general_topology():
+    """mopoe_general_train_step with a communicator (gradients, ncclAllReduce, the Adam
+    launch over the topology's segments) leaves the bits of the one-rank step."""
+    import socket
+    import torch.distributed as dist
+    parallel = import_module("2022_cambroise_interpret_multivae_amd.parallel")
+    if not dist.is_initialized():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0,
+                                world_size=1, device_id=torch.device("cuda", 0))
+    cfg = mo.Config(**C1, method="poe", enc_layers=2, dec_layers=1, dropout=0.2)
+    _, a = make_engine(cfg)
+    _, b = make_engine(cfg)
+    one = parallel.DataParallelStep(a, exchange="rccl")
+    params = mo.init_params(cfg, 0)
+    for step in range(3):
+        x = mo.make_inputs(cfg.names, cfg.input_dim, 64, seed=step)
+        noise = mo.Noise(generator=mo.noise_rng(step), mask_generator=mo.noise_rng(9 + step))
+        mo.loss_and_grads(params, cfg, x, noise)
+        one(x, eps=noise.tape, masks=noise.mask_tape)
+        b.train_step(x, eps=noise.tape, masks=noise.mask_tape)
+    torch.cuda.synchronize()
+    a.check_valid(sync=True)
+    for name in ("params", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert a.adam_steps() == b.adam_steps() == OrderedDict(clinical=3, rois=3)
+    one.rccl.close()
