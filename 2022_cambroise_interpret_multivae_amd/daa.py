@@ -26,6 +26,11 @@ def _engine(model):
 
 
 def _scale(model, name):
+    if model.engine.spec.sample_scale:
+        raise NotImplementedError(
+            "the folded DAA forwards return ONE (1, d) scale per modality; with "
+            "learn_output_sample_scale the scale is per sample and per forward -- run the "
+            "forwards one by one (model.forward) for such a model")
     return (model.engine.views["decoders.%s.logvar" % name] * 0.5).exp()
 
 

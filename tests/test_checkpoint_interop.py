@@ -21,8 +21,8 @@ checkpoint = import_module(_P + "checkpoint")
 experiment = import_module(_P + "multimodal_cohort.experiment")
 
 
-def _flags(tmp, device="cpu", method="joint_elbo"):
-    cfg = mo.Config(["clinical", "rois"], [7, 444], [3, 20], method=method)
+def _flags(tmp, device="cpu", method="joint_elbo", **topo):
+    cfg = mo.Config(["clinical", "rois"], [7, 444], [3, 20], method=method, **topo)
     flags = make_flags(cfg, device)
     flags.dir_checkpoints = os.path.join(tmp, "checkpoints")
     flags.dir_experiment_run = tmp
@@ -71,16 +71,19 @@ def test_layout_pick_rule_and_safe_loaders(tmp_path):
 
 
 @pytest.mark.reference
-def test_reference_model_and_ours_read_each_others_checkpoints(tmp_path):
+@pytest.mark.parametrize("topo", [{}, dict(enc_layers=2, dec_layers=1, dropout=0.2),
+                                  dict(enc_layers=0, dec_layers=2, sample_scale=True)],
+                         ids=["default", "enc2_dec1_drop", "enc0_dec2_sample_scale"])
+def test_reference_model_and_ours_read_each_others_checkpoints(tmp_path, topo):
     import ref_harness as rh
     if not rh.reference_available():
         pytest.skip("needs /root/reference (development container)")
     ns = rh.import_reference()
-    cfg, flags = _flags(str(tmp_path))
+    cfg, flags = _flags(str(tmp_path), **topo)
     ours = experiment.MultimodalExperiment(flags).models
     ours.load_state_dict(mo.init_params(cfg, 3))
     path = checkpoint.save_model(ours, flags, 7)
-    rflags = rh.make_flags(cfg.input_dim, cfg.style_dim)
+    rflags = rh.make_flags(cfg.input_dim, cfg.style_dim, **topo)
     ref = rh.build_experiment(ns, rflags, cfg.names).models
     missing, unexpected = ref.load_state_dict(torch.load(path, weights_only=True), strict=True)
     assert not missing and not unexpected
