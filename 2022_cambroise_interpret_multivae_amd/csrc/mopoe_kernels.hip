@@ -2835,3 +2835,4 @@ int mopoe_comm_destroy(mopoe_comm* c) {
 }  // extern "C"
 
 #include "mopoe_rccl.inc"
+#include "mopoe_sampler.inc"

@@ -130,8 +130,56 @@ class MissingModalitySampler(torch.utils.data.Sampler):
         return sum((len(idx) + size - 1) // size
                    for idx in self.dataset.idx_per_modality_subset)
 
+    def _subset_arrays(self):
+        """The per-subset index lists as (prefix offsets, one int64 array), built once."""
+        cache = getattr(self.dataset, "_subset_flat", None)
+        if cache is None or cache[0] is not self.dataset.idx_per_modality_subset:
+            parts = [np.asarray(p, dtype=np.int64) for p in self.dataset.idx_per_modality_subset]
+            begin = np.zeros(len(parts) + 1, dtype=np.int64)
+            begin[1:] = np.cumsum([len(p) for p in parts])
+            items = np.concatenate(parts) if parts else np.zeros(0, np.int64)
+            cache = (self.dataset.idx_per_modality_subset, begin, np.ascontiguousarray(items))
+            self.dataset._subset_flat = cache
+        return cache[1], cache[2]
+
+    @staticmethod
+    def draw_from(state, begin, items, batch_size):
+        """One epoch drawn from a GIVEN legacy RandomState state tuple (np.random.get_state()):
+        mopoe_sampler_epoch -- MT19937, random_interval and the shuffle of numpy's legacy
+        generator restated in C, bit for bit the draws of `draw_numpy`.  Returns (the state
+        after the draws, items, batch offsets, modality subset of every batch).  Touches no
+        global state, so a helper thread may run it ahead of time."""
+        import ctypes as C
+        if state[0] != "MT19937":
+            raise ValueError("the legacy global RandomState is MT19937")
+        key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+        pos = C.c_int32(int(state[2]))
+        bs = int(batch_size)
+        lens = np.diff(begin)
+        max_batches = int(((lens + bs - 1) // bs).sum())
+        out_items = np.empty(len(items), dtype=np.int64)
+        out_begin = np.zeros(max_batches + 1, dtype=np.int64)
+        out_subset = np.zeros(max(max_batches, 1), dtype=np.int32)
+        nb = C.c_int64(0)
+        L.check(L.lib.mopoe_sampler_epoch(
+            key.ctypes.data, C.byref(pos), len(lens), begin.ctypes.data, items.ctypes.data, bs,
+            out_items.ctypes.data, out_begin.ctypes.data, out_subset.ctypes.data, C.byref(nb)),
+            "mopoe_sampler_epoch")
+        n = int(nb.value)
+        return (("MT19937", key, int(pos.value)) + tuple(state[3:]), out_items,
+                out_begin[:n + 1], out_subset[:n])
+
     def draw(self, batch_size):
-        """The reference's epoch for this batch size (its np.random stream)."""
+        """The reference's epoch for this batch size, off numpy's global legacy stream (which
+        is left where the reference's own draws would have left it)."""
+        begin, items = self._subset_arrays()
+        state, out_items, out_begin, _ = self.draw_from(np.random.get_state(), begin, items,
+                                                        batch_size)
+        np.random.set_state(state)
+        return [out_items[out_begin[k]:out_begin[k + 1]] for k in range(len(out_begin) - 1)]
+
+    def draw_numpy(self, batch_size):
+        """The same epoch through numpy itself (the C draw's checker in the tests)."""
         indices, complete, incomplete = [], [], []
         batch_idx = 0
         for idx, _ in enumerate(self.dataset.modality_subsets):
@@ -254,9 +302,88 @@ class ResidentCohort:
         index vectors go to the device in one transfer."""
         return [(i, r) for i, r, _ in self.epoch_schedule(batch_size)]
 
+    # ---------------------------------------------------------------- epoch schedule
+    def _host_schedule(self, state, batch_size):
+        """Everything of an epoch that is host work, from a GIVEN RandomState state: the
+        sampler's draws (one C call) and, per modality, the block rows of every batch that
+        holds it, as ONE pinned int32 vector.  No global state is touched, so the helper
+        thread of `epoch_schedule` runs this for the NEXT epoch while the GPU is busy."""
+        sampler = MissingModalitySampler(self.dataset, batch_size)
+        begin, items = sampler._subset_arrays()
+        after, out_items, out_begin, out_subset = sampler.draw_from(state, begin, items,
+                                                                    batch_size)
+        idx = out_items
+        if self.dataset.indices is not None:
+            if self._indices is None:
+                self._indices = np.asarray(self.dataset.indices)
+            idx = self._indices[idx]
+        lens = np.diff(out_begin)
+        mods_of = self.dataset.modality_subsets
+        rows, starts = {}, {}
+        for mod in self.dataset.modalities:
+            has = np.array([mod in mods_of[s] for s in out_subset], dtype=bool)
+            sel = np.repeat(has, lens)
+            r = self.rows[mod][idx[sel]]
+            if (r < 0).any():
+                raise ValueError("a batch of the sampler mixes samples with and without %r" % mod)
+            t = torch.from_numpy(r.astype(np.int32))
+            rows[mod] = t.pin_memory() if self.device.type == "cuda" else t
+            st = np.full(len(lens), -1, dtype=np.int64)
+            st[has] = np.concatenate(([0], np.cumsum(lens[has])[:-1])) if has.any() else []
+            starts[mod] = st
+        return dict(after=after, lens=lens, rows=rows, starts=starts)
+
+    @staticmethod
+    def _same_state(a, b):
+        return a[0] == b[0] and a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and \
+            np.array_equal(a[1], b[1])
+
     def epoch_schedule(self, batch_size, world=1, rank=0):
         """One epoch of (inputs, row_index, loss_scale) for rank `rank` of `world`
-        data-parallel replicas (MissingModalitySampler's rank-aware schedule)."""
+        data-parallel replicas (MissingModalitySampler's rank-aware schedule).
+
+        One process: the epoch's host work is one C call + a few numpy gathers, and the NEXT
+        epoch's is started right away in a helper thread, speculating that nobody draws from
+        numpy's global generator in between (the reference's loop does not).  The speculation
+        is checked: the prefetched epoch is used only if np.random is exactly in the state it
+        was drawn from -- otherwise it is thrown away and the epoch drawn afresh, so the
+        global stream always reads as if the reference's sampler had drawn at this moment."""
+        if world > 1:
+            return self._epoch_schedule_ranks(batch_size, world, rank)
+        import threading
+        now = np.random.get_state()
+        host = None
+        pre, self._prefetch = getattr(self, "_prefetch", None), None
+        if pre is not None:
+            pre["thread"].join()
+            if pre["batch_size"] == batch_size and "host" in pre and self._same_state(pre["state"], now):
+                host = pre["host"]
+        if host is None:
+            host = self._host_schedule(now, batch_size)
+        np.random.set_state(host["after"])
+        nxt = dict(batch_size=batch_size, state=host["after"])
+
+        def work():
+            try:
+                nxt["host"] = self._host_schedule(nxt["state"], batch_size)
+            except Exception:        # (surfaces when that epoch is drawn in the foreground)
+                pass
+        nxt["thread"] = threading.Thread(target=work, daemon=True)
+        nxt["thread"].start()
+        self._prefetch = nxt
+        dev = {mod: t.to(self.device, non_blocking=True) for mod, t in host["rows"].items()}
+        out = []
+        for k, n in enumerate(host["lens"].tolist()):
+            inputs, row_index = {}, {}
+            for mod in self.dataset.modalities:
+                s = int(host["starts"][mod][k])
+                if s >= 0:
+                    inputs[mod] = self.x[mod]
+                    row_index[mod] = dev[mod][s:s + n]
+            out.append((inputs, row_index, 1.0))
+        return out
+
+    def _epoch_schedule_ranks(self, batch_size, world, rank):
         sampler = MissingModalitySampler(self.dataset, batch_size, world=world, rank=rank)
         batches = list(sampler)
         scales = list(sampler.loss_scales)

@@ -187,10 +187,19 @@ class StepRetry:
         return out
 
     def flush(self):
-        """End of an epoch: nothing invalid is left behind (synchronises)."""
+        """Nothing invalid is left behind (synchronises)."""
         if self._look():
             self._redo()
         self.history.clear()
+
+    def end_epoch(self):
+        """End of an epoch.  Replicas look synchronously (they must decide together); one
+        process reads the pinned mirror without waiting for the GPU -- a step that fails
+        after this look is retried at the next one (`history` keeps its batch)."""
+        if self.world > 1:
+            self.flush()
+        elif int(self.engine.status_host[1]) != 0:
+            self._redo()
 
     def _look(self):
         self._since = 0

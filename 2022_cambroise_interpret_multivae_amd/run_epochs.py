@@ -175,8 +175,13 @@ def train(model_idx, epoch, exp, tb_logger):
                 plan, ws = step(inputs, row_index=row_index, loss_scale=weight)
             _log_step(tb_logger, eng, plan, ws)
         if guard is not None:
-            guard.flush()               # (a step that could not be completed is run again)
-        eng.check_valid(sync=True)      # no half-applied step leaves the epoch unnoticed
+            # One process: no synchronisation at the end of an epoch -- the kernels' pinned
+            # mirror is looked at (a step that failed late is retried at the next look: the
+            # parameters are those of the last complete step meanwhile, run_epochs() looks
+            # synchronously after the last epoch).  Replicas look synchronously, together.
+            guard.end_epoch()
+        else:
+            eng.check_valid(sync=True)  # no half-applied step leaves the epoch unnoticed
         return
     if world > 1:
         raise NotImplementedError(
@@ -266,6 +271,9 @@ def run_epochs(exp, tb_logger=None):
             train(model_idx, epoch, exp, tb_logger)
             test(model_idx, epoch, exp, tb_logger)
             due = (epoch + 1) % 5 == 0 or epoch + 1 == flags.end_epoch
+            if due:                      # (nothing half-done goes into a checkpoint)
+                for guard in exp.__dict__.get("_retry_guards", {}).values():
+                    guard.flush()
             if due and parallel.rank() == 0:
                 checkpoint.save_model(exp.models[model_idx] if many else exp.models, flags,
                                       epoch, model_idx if many else None)

@@ -280,6 +280,56 @@ def regime_point(device, n=65536):
     return out
 
 
+def loop_figure(device, subjects, batch=256, epochs=20):
+    """The drop-in loop (SURVEY.md 8d's second number): run_epochs.train of the mirror
+    package over a ResidentCohort -- a synthetic cohort of `subjects` subjects, 20 % of them
+    lacking one block, blocks resident in HBM, the reference's MissingModalitySampler draws
+    (its legacy np.random stream, restated in C and drawn one epoch ahead by a helper thread),
+    index batches gathered by the kernels, one fused step per batch, the retry policy's
+    per-step look.  us per step next to the bare engine loop of `value`."""
+    import types
+    import numpy as np
+    from importlib import import_module
+    P = "2022_cambroise_interpret_multivae_amd."
+    ds_mod = import_module(P + "multimodal_cohort.dataset")
+    run_epochs = import_module(P + "run_epochs")
+    c = CONFIGS["C1"]
+    rng = np.random.RandomState(0)
+    lacks, which = rng.rand(subjects) < 0.2, rng.rand(subjects) < 0.5
+    has = {"clinical": ~(lacks & which), "rois": ~(lacks & ~which)}
+    data, idx = {}, {}
+    for mod, dim in zip(c["names"], c["dims"]):
+        rows = np.flatnonzero(has[mod])
+        data[mod] = rng.randn(len(rows), dim)
+        col = np.empty(subjects, dtype=object)
+        col[:] = None
+        for k, subj in enumerate(rows):
+            col[subj] = k
+        idx[mod] = col
+    ds = ds_mod.MultimodalDataset(data, idx)
+    cohort = ds_mod.ResidentCohort(ds, device, scalers=ds_mod.fit_scalers(ds))
+    eng = mm.MoPoEEngine(make_spec(c), device, seed=7)
+    eng.reset_parameters(torch.Generator().manual_seed(0))
+    exp = types.SimpleNamespace(
+        flags=types.SimpleNamespace(num_models=1, batch_size=batch, grad_scaling=False),
+        models=types.SimpleNamespace(engine=eng, train=lambda: None), dataset_train=cohort,
+        optimizers=types.SimpleNamespace(_sync=lambda: None))
+    steps = len(ds_mod.MissingModalitySampler(ds, batch))
+    np.random.seed(1)
+    for _ in range(3):
+        run_epochs.train(0, 0, exp, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        run_epochs.train(0, 0, exp, None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.check_valid(sync=True)
+    return {"subjects": subjects, "batch": batch, "steps_per_epoch": steps, "epochs": epochs,
+            "us_per_step": round(1e6 * dt / (epochs * steps), 2),
+            "samples_per_s": round(epochs * subjects / dt, 1)}
+
+
 def oracle_setup(c):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mopoe_oracle as mo
@@ -677,6 +727,12 @@ def main():
     single = rank == 0 and world == 1 and dist is None
     if single and not args.quick:
         out["other_configs"] = {k: other_config(k, device) for k in ("C3", "C5")}
+        out["loop"] = {"what": "run_epochs.train over a ResidentCohort (sampler + index "
+                               "batches + fused steps + per-step validity look), not the "
+                               "headline: the drop-in loop a user of the reference gets",
+                       "cohorts": [loop_figure(device, 3000), loop_figure(device, 16384)]}
+        for c_ in out["loop"]["cohorts"]:
+            c_["ratio_to_bare_engine_loop"] = round(c_["us_per_step"] / (1e3 * out["ms_per_step"]), 3)
         out["regime_n65536"] = regime_point(device)
         out["eager_rocm_baseline"] = eager_rocm_baseline(device)
     if single and not args.no_cpu_baseline:

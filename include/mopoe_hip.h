@@ -512,6 +512,27 @@ int mopoe_rccl_train_step(mopoe_rccl* comm, const mopoe_model* model, const mopo
 int mopoe_rccl_allreduce(mopoe_rccl* comm, float* data, int64_t count, void* stream);
 int mopoe_rccl_destroy(mopoe_rccl* comm);
 
+/* ---------------------------------------------------------------------------
+ * HOST function (no device work, no stream): one epoch of the reference's
+ * MissingModalitySampler (multimodal_cohort/dataset.py:296-354, non-stratified path) --
+ * batches whose samples all have the same modality subset, drawn with
+ * np.random.choice(rest, size, replace=False) until a subset is used up, the complete
+ * batches then the incomplete ones, each group in an np.random.choice order -- bit for bit
+ * the draws of numpy's legacy global RandomState:
+ *   mt_key / mt_pos   in: np.random.get_state()[1] (624 uint32) and [2]; out: the state
+ *                     after the epoch's draws (np.random.set_state it back)
+ *   subset_begin      (num_subsets + 1) prefix offsets into subset_items, the sample
+ *                     indices of every modality subset (dataset.idx_per_modality_subset)
+ *   out_items         (total samples) the epoch, batch after batch
+ *   out_begin         (number of batches + 1) offsets into out_items; the caller sizes it
+ *                     sum(ceil(len_s / batch_size)) + 1
+ *   out_subset        (number of batches) the modality subset each batch came from
+ * ------------------------------------------------------------------------- */
+int mopoe_sampler_epoch(uint32_t* mt_key, int32_t* mt_pos, int32_t num_subsets,
+                        const int64_t* subset_begin, const int64_t* subset_items,
+                        int64_t batch_size, int64_t* out_items, int64_t* out_begin,
+                        int32_t* out_subset, int64_t* num_batches);
+
 /* Free functions of section 8b, float32 device tensors. */
 
 /* torch.nn.Linear (+ optional ReLU) as used by Encoder.forward / Decoder.forward

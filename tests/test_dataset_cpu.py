@@ -88,3 +88,77 @@ def test_scaler_reproduces_the_reference_transform_chain():
         want = z["transformed/" + mod]
         assert got.dtype == want.dtype == np.float32
         assert np.allclose(got, want, rtol=2e-7, atol=1e-7), np.abs(got - want).max()
+
+
+def _cohort(n, seed):
+    rng = np.random.RandomState(seed)
+    has = {"clinical": rng.rand(n) > 0.15, "rois": rng.rand(n) > 0.25}
+    has["clinical"] |= ~has["rois"]
+    data, idx = {}, {}
+    for mod, h in has.items():
+        data[mod] = rng.randn(int(h.sum()), 3)
+        col = np.empty(n, dtype=object)
+        col[:] = None
+        for k, s in enumerate(rng.permutation(np.flatnonzero(h))):
+            col[s] = k
+        idx[mod] = col
+    return ds_mod.MultimodalDataset(data, idx)
+
+
+@pytest.mark.parametrize("n,bs,seed", [(101, 16, 7), (640, 64, 1), (17, 1, 2), (5, 8, 3),
+                                        (3000, 256, 4), (1, 4, 5), (2100, 2, 6)])
+def test_c_sampler_draws_numpys_legacy_stream_bit_for_bit(n, bs, seed):
+    """mopoe_sampler_epoch (MT19937 + random_interval + the legacy shuffle restated in C)
+    against numpy itself: the same batches, and numpy's global generator left in the same
+    state -- position included -- as after the reference's own np.random.choice calls."""
+    ds = _cohort(n, seed)
+    smp = ds_mod.MissingModalitySampler(ds, bs)
+    np.random.seed(seed)
+    np.random.rand(seed * 37 % 700)          # (start somewhere inside a block of 624)
+    start = np.random.get_state()
+    want = smp.draw_numpy(bs)
+    after, probe = np.random.get_state(), np.random.rand(3)
+    np.random.set_state(start)
+    got = smp.draw(bs)
+    assert len(got) == len(want) == len(smp)
+    for g, w in zip(got, want):
+        assert g.dtype == np.int64 and np.array_equal(g, w)
+    mine = np.random.get_state()
+    assert mine[2] == after[2] and np.array_equal(mine[1], after[1])
+    assert np.array_equal(np.random.rand(3), probe)
+
+
+def test_prefetched_epochs_are_the_epochs_of_the_sampler():
+    """ResidentCohort.epoch_schedule draws the NEXT epoch ahead in a helper thread; what the
+    loop sees -- batches AND numpy's global stream -- is what drawing at the moment of the
+    call would have given, also when somebody else uses np.random in between."""
+    ds = _cohort(700, 9)
+    cohort = ds_mod.ResidentCohort(ds, "cpu")
+    twin = ds_mod.MissingModalitySampler(ds, 64)
+
+    def rows_of(schedule):
+        return [{m: r.numpy().copy() for m, r in row_index.items()} for _, row_index, _ in schedule]
+
+    np.random.seed(3)
+    got = [rows_of(cohort.epoch_schedule(64)) for _ in range(2)]
+    np.random.rand(5)                         # an outsider draws: the prefetched epoch is void
+    got.append(rows_of(cohort.epoch_schedule(64)))
+    got.append(rows_of(cohort.epoch_schedule(32)))   # another batch size: void as well
+    tail = np.random.rand(2)
+    np.random.seed(3)
+    want = []
+    for k, bs in enumerate((64, 64, 64, 32)):
+        if k == 2:
+            np.random.rand(5)
+        epoch = []
+        for b in twin.draw_numpy(bs):
+            inputs, row_index = cohort.batch(b)
+            epoch.append({m: r.numpy() for m, r in row_index.items()})
+        want.append(epoch)
+    assert np.array_equal(np.random.rand(2), tail)
+    for g, w in zip(got, want):
+        assert len(g) == len(w)
+        for gb, wb in zip(g, w):
+            assert gb.keys() == wb.keys()
+            for m in gb:
+                assert np.array_equal(gb[m], wb[m])
