@@ -204,6 +204,8 @@ SYMBOLS = {
                                           C.POINTER(Buffers), C.POINTER(Adam), _i32, _ptr]),
     "mopoe_sampler_epoch": (C.c_int, [_ptr, C.POINTER(_i32), _i32, _ptr, _ptr, C.c_int64, _ptr,
                                       _ptr, _ptr, C.POINTER(C.c_int64)]),
+    "mopoe_sampler_rows": (C.c_int, [_i32, C.c_int64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                     _ptr]),
     "mopoe_rccl_unique_id": (C.c_int, [_ptr]),
     "mopoe_rccl_create": (C.c_int, [_i32, _i32, _ptr, C.POINTER(_ptr)]),
     "mopoe_rccl_train_step": (C.c_int, [_ptr, C.POINTER(Model), C.POINTER(Step),

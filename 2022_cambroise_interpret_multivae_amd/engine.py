@@ -15,6 +15,43 @@ from . import _lib as L
 from .plan import ModelSpec
 
 
+class IndexBatch:
+    """A batch as the kernels take it: `x` = {modality: the resident block (rows, d_m)} of
+    the modalities every sample has, `n` rows, `row_ptr` = {modality: DEVICE ADDRESS of the n
+    int32 block rows} (mopoe_buffers.row_index), `keep` = whatever owns that memory.  What
+    ResidentCohort.epoch_schedule hands the loop: engine.train_step / forward take it as the
+    `batch` argument without building a tensor per batch."""
+    __slots__ = ("x", "n", "row_ptr", "keep")
+
+    def __init__(self, x, n, row_ptr, keep):
+        self.x, self.n, self.row_ptr, self.keep = x, n, row_ptr, keep
+
+    def keys(self):
+        return self.x.keys()
+
+    def __contains__(self, name):
+        return name in self.x
+
+    def __iter__(self):
+        return iter(self.x)
+
+    def __getitem__(self, name):
+        return self.x[name]
+
+    def items(self):
+        return self.x.items()
+
+    def row_index(self):
+        """{modality: (n,) int32 device tensor}: the gather vectors as tensors (tests, the
+        slower paths)."""
+        dev = self.keep[0]
+        out = {}
+        for m, p in self.row_ptr.items():
+            s = (p - dev[m].data_ptr()) // 4
+            out[m] = dev[m][s:s + self.n]
+        return out
+
+
 class Workspace:
     """Caller-owned buffers of one (batch size, jobs-per-modality) shape."""
 
@@ -137,6 +174,7 @@ class MoPoEEngine:
         # writes: an invalid step is noticed without synchronising (check_valid)
         self.status_host = torch.zeros(4, dtype=torch.int32).pin_memory() \
             if self._on_gpu else torch.zeros(4, dtype=torch.int32)
+        self._status = self.status_host.numpy()
         self.device = self.params.device   # with its index: cheap `is it already there` tests
         self.views = spec.param_views(self.params)
         self.grad_views = spec.param_views(self.grads)
@@ -193,7 +231,7 @@ class MoPoEEngine:
             torch.cuda.synchronize(self.device)
             bad = int(self.counters[L.CTR_INVALID].item())
         else:
-            bad = int(self.status_host[1])
+            bad = int(self._status[1])      # (a numpy view of the pinned mirror: no tensor op)
         if bad:
             raise L.MopoeError(
                 "a training step could not be completed (%d event(s): hand-off / "
@@ -352,7 +390,8 @@ class MoPoEEngine:
                 b.x[m] = L.ptr(t)
                 b.x_rows[m] = t.shape[0]
                 ri = row_index.get(name) if row_index is not None else None
-                b.row_index[m] = L.ptr(ri) if ri is not None else None
+                b.row_index[m] = None if ri is None else \
+                    C.c_void_p(ri) if isinstance(ri, int) else L.ptr(ri)
             else:
                 b.x[m] = None
                 b.x_rows[m] = 0
@@ -367,6 +406,8 @@ class MoPoEEngine:
         L.require_gpu()
         if not self._on_gpu:
             raise L.MopoeError("engine was created on %s" % self.device)
+        if isinstance(batch, IndexBatch):     # resident blocks + addresses: nothing to prepare
+            return batch.x, batch.n, batch.row_ptr
         if row_index is not None and not isinstance(row_index, dict):
             row_index = {name: row_index for name in batch}
         if row_index is not None:
@@ -495,7 +536,7 @@ class MoPoEEngine:
         else:
             L.check(L.lib.mopoe_train_step(self.spec.c_model, step, buf, adam,
                                            L.stream_ptr()), "mopoe_train_step")
-        self._keep = (x, keep, row_index)
+        self._keep = (batch, x, keep, row_index)
         self._train_calls += 1
         self.last_present_mask = step.present_mask
         return plan, ws

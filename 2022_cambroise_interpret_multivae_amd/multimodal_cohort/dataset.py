@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
+from ..engine import IndexBatch
 
 
 class MultimodalDataset(torch.utils.data.Dataset):
@@ -284,7 +285,7 @@ class ResidentCohort:
         idx = np.asarray(sample_indices, dtype=np.int64)
         if self.dataset.indices is not None:
             if self._indices is None:
-                self._indices = np.asarray(self.dataset.indices)
+                self._indices = np.ascontiguousarray(self.dataset.indices, dtype=np.int64)
             idx = self._indices[idx]
         inputs, row_index = {}, {}
         for mod in self.dataset.modalities:
@@ -300,38 +301,49 @@ class ResidentCohort:
     def epoch(self, batch_size):
         """One epoch of (inputs, row_index) in MissingModalitySampler order; all
         index vectors go to the device in one transfer."""
-        return [(i, r) for i, r, _ in self.epoch_schedule(batch_size)]
+        out = []
+        for i, r, _ in self.epoch_schedule(batch_size):
+            out.append((dict(i.x), i.row_index()) if isinstance(i, IndexBatch) else (i, r))
+        return out
 
     # ---------------------------------------------------------------- epoch schedule
     def _host_schedule(self, state, batch_size):
         """Everything of an epoch that is host work, from a GIVEN RandomState state: the
-        sampler's draws (one C call) and, per modality, the block rows of every batch that
-        holds it, as ONE pinned int32 vector.  No global state is touched, so the helper
-        thread of `epoch_schedule` runs this for the NEXT epoch while the GPU is busy."""
+        sampler's draws and, per modality, the block rows of every batch that holds it as
+        ONE pinned int32 vector -- two C calls (the GIL is released meanwhile).  No global
+        state is touched, so the helper thread of `epoch_schedule` runs this for the NEXT
+        epoch while the GPU is busy with the current one."""
+        import ctypes as C
         sampler = MissingModalitySampler(self.dataset, batch_size)
         begin, items = sampler._subset_arrays()
         after, out_items, out_begin, out_subset = sampler.draw_from(state, begin, items,
                                                                     batch_size)
-        idx = out_items
+        mods = self.dataset.modalities
+        nb, M = len(out_subset), len(mods)
+        lens = np.diff(out_begin)
+        has = np.array([[m in sub for m in mods] for sub in self.dataset.modality_subsets],
+                       dtype=np.uint8)
+        per_batch = has[out_subset].astype(bool) if nb else np.zeros((0, M), bool)
+        indices = None
         if self.dataset.indices is not None:
             if self._indices is None:
-                self._indices = np.asarray(self.dataset.indices)
-            idx = self._indices[idx]
-        lens = np.diff(out_begin)
-        mods_of = self.dataset.modality_subsets
+                self._indices = np.ascontiguousarray(self.dataset.indices, dtype=np.int64)
+            indices = self._indices
         rows, starts = {}, {}
-        for mod in self.dataset.modalities:
-            has = np.array([mod in mods_of[s] for s in out_subset], dtype=bool)
-            sel = np.repeat(has, lens)
-            r = self.rows[mod][idx[sel]]
-            if (r < 0).any():
-                raise ValueError("a batch of the sampler mixes samples with and without %r" % mod)
-            t = torch.from_numpy(r.astype(np.int32))
-            rows[mod] = t.pin_memory() if self.device.type == "cuda" else t
-            st = np.full(len(lens), -1, dtype=np.int64)
-            st[has] = np.concatenate(([0], np.cumsum(lens[has])[:-1])) if has.any() else []
-            starts[mod] = st
-        return dict(after=after, lens=lens, rows=rows, starts=starts)
+        for k, mod in enumerate(mods):
+            t = torch.empty(int(lens[per_batch[:, k]].sum()) if nb else 0, dtype=torch.int32)
+            rows[mod] = t.pin_memory() if self.device.type == "cuda" and t.numel() else t
+            starts[mod] = np.empty(nb, dtype=np.int64)
+        ptrs = lambda seq: (C.c_void_p * M)(*seq)
+        L.check(L.lib.mopoe_sampler_rows(
+            M, nb, out_items.ctypes.data, np.ascontiguousarray(out_begin).ctypes.data,
+            np.ascontiguousarray(out_subset).ctypes.data, np.ascontiguousarray(has).ctypes.data,
+            indices.ctypes.data if indices is not None else None,
+            ptrs(self.rows[m].ctypes.data for m in mods),
+            ptrs(rows[m].data_ptr() for m in mods),
+            ptrs(starts[m].ctypes.data for m in mods)), "mopoe_sampler_rows")
+        return dict(after=after, lens=lens.tolist(), rows=rows,
+                    starts={m: v.tolist() for m, v in starts.items()})
 
     @staticmethod
     def _same_state(a, b):
@@ -342,45 +354,51 @@ class ResidentCohort:
         """One epoch of (inputs, row_index, loss_scale) for rank `rank` of `world`
         data-parallel replicas (MissingModalitySampler's rank-aware schedule).
 
-        One process: the epoch's host work is one C call + a few numpy gathers, and the NEXT
-        epoch's is started right away in a helper thread, speculating that nobody draws from
+        One process: `inputs` is an IndexBatch (the resident blocks + the addresses of the
+        batch's gather vectors inside ONE device tensor per modality: no per-batch tensor is
+        made) and row_index is None.  The epoch's host work is two C calls, and the NEXT
+        epoch's is started right away on a helper thread, speculating that nobody draws from
         numpy's global generator in between (the reference's loop does not).  The speculation
         is checked: the prefetched epoch is used only if np.random is exactly in the state it
         was drawn from -- otherwise it is thrown away and the epoch drawn afresh, so the
         global stream always reads as if the reference's sampler had drawn at this moment."""
         if world > 1:
             return self._epoch_schedule_ranks(batch_size, world, rank)
-        import threading
         now = np.random.get_state()
         host = None
         pre, self._prefetch = getattr(self, "_prefetch", None), None
         if pre is not None:
-            pre["thread"].join()
-            if pre["batch_size"] == batch_size and "host" in pre and self._same_state(pre["state"], now):
-                host = pre["host"]
+            try:
+                ahead = pre["future"].result()
+            except Exception:      # (the same error surfaces from the foreground draw below)
+                ahead = None
+            if ahead is not None and pre["batch_size"] == batch_size and \
+                    self._same_state(pre["state"], now):
+                host = ahead
         if host is None:
             host = self._host_schedule(now, batch_size)
         np.random.set_state(host["after"])
-        nxt = dict(batch_size=batch_size, state=host["after"])
-
-        def work():
-            try:
-                nxt["host"] = self._host_schedule(nxt["state"], batch_size)
-            except Exception:        # (surfaces when that epoch is drawn in the foreground)
-                pass
-        nxt["thread"] = threading.Thread(target=work, daemon=True)
-        nxt["thread"].start()
-        self._prefetch = nxt
-        dev = {mod: t.to(self.device, non_blocking=True) for mod, t in host["rows"].items()}
+        if getattr(self, "_pool", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mopoe-sampler")
+        self._prefetch = dict(batch_size=batch_size, state=host["after"],
+                              future=self._pool.submit(self._host_schedule, host["after"],
+                                                       batch_size))
+        mods = self.dataset.modalities
+        dev = {m: host["rows"][m].to(self.device, non_blocking=True) for m in mods}
+        base = {m: dev[m].data_ptr() for m in mods}
+        xs = [self.x[m] for m in mods]
+        starts = [host["starts"][m] for m in mods]
+        keep = (dev, host["rows"])          # (the pinned source outlives the copy)
         out = []
-        for k, n in enumerate(host["lens"].tolist()):
-            inputs, row_index = {}, {}
-            for mod in self.dataset.modalities:
-                s = int(host["starts"][mod][k])
+        for k, n in enumerate(host["lens"]):
+            x, ptr = {}, {}
+            for m, t, st in zip(mods, xs, starts):
+                s = st[k]
                 if s >= 0:
-                    inputs[mod] = self.x[mod]
-                    row_index[mod] = dev[mod][s:s + n]
-            out.append((inputs, row_index, 1.0))
+                    x[m] = t
+                    ptr[m] = base[m] + 4 * s
+            out.append((IndexBatch(x, n, ptr, keep), None, 1.0))
         return out
 
     def _epoch_schedule_ranks(self, batch_size, world, rank):

@@ -171,6 +171,8 @@ class StepRetry:
         self.depth = int(depth)
         self.world = world_size() if world is None else world
         self.history = collections.deque(maxlen=self.depth)
+        # (numpy view of the pinned host mirror the kernels write: a read costs no tensor op)
+        self._mirror = engine.status_host.numpy()
         self.retries = 0
         self._since = 0
 
@@ -179,7 +181,7 @@ class StepRetry:
         self.history.append((args, kw))
         self._since += 1
         if self.world == 1:
-            bad = int(self.engine.status_host[1]) != 0
+            bad = self._mirror[1] != 0
         else:
             bad = self._since >= max(1, self.depth // 2) and self._look()
         if bad:
@@ -198,7 +200,7 @@ class StepRetry:
         after this look is retried at the next one (`history` keeps its batch)."""
         if self.world > 1:
             self.flush()
-        elif int(self.engine.status_host[1]) != 0:
+        elif self._mirror[1] != 0:
             self._redo()
 
     def _look(self):

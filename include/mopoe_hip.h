@@ -532,6 +532,18 @@ int mopoe_sampler_epoch(uint32_t* mt_key, int32_t* mt_pos, int32_t num_subsets,
                         const int64_t* subset_begin, const int64_t* subset_items,
                         int64_t batch_size, int64_t* out_items, int64_t* out_begin,
                         int32_t* out_subset, int64_t* num_batches);
+/* HOST function: the gather vectors of those batches over per-modality blocks resident in
+ * HBM (mopoe_buffers.row_index).  rows[k] (subjects) = block row of a subject in modality
+ * k's block or -1 (reference dataset.py:99-126: idx_per_mod); indices = the dataset's
+ * optional subject subset (dataset.indices) or NULL; subset_has[s * num_mods + k] = modality
+ * subset s holds modality k.  out_rows[k] receives the rows of every batch that holds k,
+ * batch after batch (sized by the caller: the samples of those batches), out_start[k][b]
+ * the offset of batch b in it or -1. */
+int mopoe_sampler_rows(int32_t num_mods, int64_t num_batches, const int64_t* items,
+                       const int64_t* batch_begin, const int32_t* batch_subset,
+                       const uint8_t* subset_has, const int64_t* indices,
+                       const int64_t* const* rows, int32_t* const* out_rows,
+                       int64_t* const* out_start);
 
 /* Free functions of section 8b, float32 device tensors. */
 

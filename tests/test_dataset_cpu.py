@@ -137,7 +137,8 @@ def test_prefetched_epochs_are_the_epochs_of_the_sampler():
     twin = ds_mod.MissingModalitySampler(ds, 64)
 
     def rows_of(schedule):
-        return [{m: r.numpy().copy() for m, r in row_index.items()} for _, row_index, _ in schedule]
+        return [{m: r.numpy().copy() for m, r in batch.row_index().items()}
+                for batch, _, _ in schedule]
 
     np.random.seed(3)
     got = [rows_of(cohort.epoch_schedule(64)) for _ in range(2)]

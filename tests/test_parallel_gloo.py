@@ -76,6 +76,8 @@ class OracleEngine:
     def train_step(self, batch, eps=None, row_index=None, apply_adam=True, loss_scale=1.0,
                    stats_host=None, comm=None):
         self.check_valid()
+        if row_index is None:       # an IndexBatch of ResidentCohort.epoch_schedule
+            row_index = batch.row_index()
         x = OrderedDict((k, batch[k][row_index[k].long()]) for k in self.cfg.names if k in batch)
         first = next(iter(x))
         step = int(self.counters[L.CTR_STEPS_BEGUN]) + 1
