@@ -307,7 +307,19 @@ class ResidentCohort:
         return out
 
     # ---------------------------------------------------------------- epoch schedule
-    def _host_schedule(self, state, batch_size):
+    def _staging(self, slot):
+        """Pinned int32 staging vectors of one epoch (a row per sample at most), two sets used
+        in turn: allocated HERE, by the caller's thread -- the helper thread makes no device
+        runtime call at all (its first one would initialise a context of its own, ~100 ms)."""
+        pools = self.__dict__.setdefault("_pinned", {})
+        if slot not in pools:
+            n = len(self.dataset)
+            pools[slot] = {m: (torch.empty(n, dtype=torch.int32).pin_memory()
+                               if self.device.type == "cuda" else torch.empty(n, dtype=torch.int32))
+                           for m in self.dataset.modalities}
+        return pools[slot]
+
+    def _host_schedule(self, state, batch_size, staging=None):
         """Everything of an epoch that is host work, from a GIVEN RandomState state: the
         sampler's draws and, per modality, the block rows of every batch that holds it as
         ONE pinned int32 vector -- two C calls (the GIL is released meanwhile).  No global
@@ -331,8 +343,9 @@ class ResidentCohort:
             indices = self._indices
         rows, starts = {}, {}
         for k, mod in enumerate(mods):
-            t = torch.empty(int(lens[per_batch[:, k]].sum()) if nb else 0, dtype=torch.int32)
-            rows[mod] = t.pin_memory() if self.device.type == "cuda" and t.numel() else t
+            count = int(lens[per_batch[:, k]].sum()) if nb else 0
+            rows[mod] = staging[mod][:count] if staging is not None else \
+                torch.empty(count, dtype=torch.int32)
             starts[mod] = np.empty(nb, dtype=np.int64)
         ptrs = lambda seq: (C.c_void_p * M)(*seq)
         L.check(L.lib.mopoe_sampler_rows(
@@ -375,17 +388,27 @@ class ResidentCohort:
             if ahead is not None and pre["batch_size"] == batch_size and \
                     self._same_state(pre["state"], now):
                 host = ahead
+        turn = self.__dict__.get("_turn", 0)
         if host is None:
-            host = self._host_schedule(now, batch_size)
+            host = self._host_schedule(now, batch_size, self._staging(turn % 2))
         np.random.set_state(host["after"])
         if getattr(self, "_pool", None) is None:
             from concurrent.futures import ThreadPoolExecutor
             self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mopoe-sampler")
-        self._prefetch = dict(batch_size=batch_size, state=host["after"],
-                              future=self._pool.submit(self._host_schedule, host["after"],
-                                                       batch_size))
         mods = self.dataset.modalities
         dev = {m: host["rows"][m].to(self.device, non_blocking=True) for m in mods}
+        # the OTHER staging set goes to the helper thread; its last copy (the epoch before
+        # this one) must have left it
+        copied = self.__dict__.setdefault("_copied", {})
+        if self.device.type == "cuda":
+            copied[turn % 2] = torch.cuda.Event()
+            copied[turn % 2].record()
+            if (turn + 1) % 2 in copied:
+                copied[(turn + 1) % 2].synchronize()
+        self._turn = turn + 1
+        self._prefetch = dict(batch_size=batch_size, state=host["after"],
+                              future=self._pool.submit(self._host_schedule, host["after"],
+                                                       batch_size, self._staging((turn + 1) % 2)))
         base = {m: dev[m].data_ptr() for m in mods}
         xs = [self.x[m] for m in mods]
         starts = [host["starts"][m] for m in mods]

@@ -223,8 +223,9 @@ class _Scripted:
         return getattr(self._eng, name)
 
     def train_step(self, inputs, row_index=None, **kw):
-        first = next(iter(row_index))
-        rows = row_index[first]
+        ri = row_index if row_index is not None else inputs.row_index()   # (an IndexBatch)
+        first = next(iter(ri))
+        rows = ri[first]
         key = int(rows.sum().item()) * 31 + len(rows) + 7 * len(inputs)
         eps = _eps(self._cfg, len(rows), key, list(inputs))
         fail = self.calls in self._fail
