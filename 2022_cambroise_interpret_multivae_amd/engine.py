@@ -32,6 +32,9 @@ class IndexBatch:
     def __contains__(self, name):
         return name in self.x
 
+    def __len__(self):
+        return len(self.x)
+
     def __iter__(self):
         return iter(self.x)
 

@@ -312,11 +312,12 @@ class ResidentCohort:
         in turn: allocated HERE, by the caller's thread -- the helper thread makes no device
         runtime call at all (its first one would initialise a context of its own, ~100 ms)."""
         pools = self.__dict__.setdefault("_pinned", {})
-        if slot not in pools:
-            n = len(self.dataset)
-            pools[slot] = {m: (torch.empty(n, dtype=torch.int32).pin_memory()
-                               if self.device.type == "cuda" else torch.empty(n, dtype=torch.int32))
-                           for m in self.dataset.modalities}
+        if slot not in pools:     # ONE vector for all modalities: one transfer per epoch
+            n, M = len(self.dataset), len(self.dataset.modalities)
+            flat = torch.empty(n * M, dtype=torch.int32)
+            flat = flat.pin_memory() if self.device.type == "cuda" else flat
+            pools[slot] = (flat, {m: flat[k * n:(k + 1) * n]
+                                  for k, m in enumerate(self.dataset.modalities)})
         return pools[slot]
 
     def _host_schedule(self, state, batch_size, staging=None):
@@ -344,7 +345,7 @@ class ResidentCohort:
         rows, starts = {}, {}
         for k, mod in enumerate(mods):
             count = int(lens[per_batch[:, k]].sum()) if nb else 0
-            rows[mod] = staging[mod][:count] if staging is not None else \
+            rows[mod] = staging[1][mod][:count] if staging is not None else \
                 torch.empty(count, dtype=torch.int32)
             starts[mod] = np.empty(nb, dtype=np.int64)
         ptrs = lambda seq: (C.c_void_p * M)(*seq)
@@ -355,7 +356,7 @@ class ResidentCohort:
             ptrs(self.rows[m].ctypes.data for m in mods),
             ptrs(rows[m].data_ptr() for m in mods),
             ptrs(starts[m].ctypes.data for m in mods)), "mopoe_sampler_rows")
-        return dict(after=after, lens=lens.tolist(), rows=rows,
+        return dict(after=after, lens=lens.tolist(), rows=rows, staging=staging,
                     starts={m: v.tolist() for m, v in starts.items()})
 
     @staticmethod
@@ -396,12 +397,15 @@ class ResidentCohort:
             from concurrent.futures import ThreadPoolExecutor
             self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mopoe-sampler")
         mods = self.dataset.modalities
-        dev = {m: host["rows"][m].to(self.device, non_blocking=True) for m in mods}
+        n_all = len(self.dataset)
+        flat = host["staging"][0].to(self.device, non_blocking=True)      # one transfer
+        dev = {m: flat[k * n_all:(k + 1) * n_all] for k, m in enumerate(mods)}
         # the OTHER staging set goes to the helper thread; its last copy (the epoch before
         # this one) must have left it
         copied = self.__dict__.setdefault("_copied", {})
         if self.device.type == "cuda":
-            copied[turn % 2] = torch.cuda.Event()
+            if turn % 2 not in copied:
+                copied[turn % 2] = torch.cuda.Event()
             copied[turn % 2].record()
             if (turn + 1) % 2 in copied:
                 copied[(turn + 1) % 2].synchronize()
