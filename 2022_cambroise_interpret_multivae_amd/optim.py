@@ -15,8 +15,12 @@ class FusedAdam(torch.optim.Optimizer):
         self.world = 1     # > 1: engine.grads holds the sum over that many ranks
 
     def _sync(self):
+        """The kernels' Adam scalars follow param_groups (a scheduler may change lr)."""
         g = self.param_groups[0]
-        self.model.engine.adam = L.Adam(g["lr"], g["betas"][0], g["betas"][1], g["eps"])
+        now = (g["lr"], g["betas"][0], g["betas"][1], g["eps"])
+        if getattr(self, "_synced", None) != now:
+            self.model.engine.adam = L.Adam(*now)
+            self._synced = now
 
     @torch.no_grad()
     def step(self, closure=None):
