@@ -1507,11 +1507,13 @@ DEV bool adam_step_valid(const mopoe_buffers& buf, const AdamSegs& s, const floa
     }
     return ok;
 }
-// The block that finishes last ends the step: counts, next step's records, the sticky
-// word when the ranks disagreed.  (Every other block has read what it needs before it
-// takes its ticket.)
+// The block that finishes last ends the step: counts, the sticky word when the ranks
+// disagreed.  (Every other block has read what it needs before it takes its ticket.)
+// `records`: also the next step's Adam records (two pow() in double per modality, ~1.5 us
+// of one thread) -- k_xgmi-style callers; k_adam has its first block compute them while the
+// others stream (step_next_records), so the kernel's tail is a handful of integer stores.
 DEV void adam_kernel_end(const mopoe_buffers& buf, const AdamSegs& s, bool valid, int total_blocks,
-                         int tid) {
+                         int tid, bool records = true) {
     __shared__ int last;
     __syncthreads();
     if (tid == 0)
@@ -1520,7 +1522,15 @@ DEV void adam_kernel_end(const mopoe_buffers& buf, const AdamSegs& s, bool valid
     __syncthreads();
     if (!last) return;
     const int step = buf.counters[MOPOE_CTR_STEPS_BEGUN];
-    step_end(buf.counters, step, tid, s.num_mods, s.present_mask, valid, s.adam);
+    if (records) {
+        step_end(buf.counters, step, tid, s.num_mods, s.present_mask, valid, s.adam);
+    } else if (tid < s.num_mods) {
+        if (valid && ((s.present_mask >> tid) & 1)) buf.counters[MOPOE_CTR_ADAM_STEPS + tid] += 1;
+        if (tid == 0) {
+            buf.counters[kCtrBeta] = __builtin_bit_cast(int32_t, s.adam.beta1);
+            buf.counters[kCtrBeta + 1] = __builtin_bit_cast(int32_t, s.adam.beta2);
+        }
+    }
     if (tid == 0) {
         buf.counters[MOPOE_CTR_TICKET] = 0;
         if (!valid && buf.counters[MOPOE_CTR_INVALID] == 0) buf.counters[MOPOE_CTR_INVALID] = 1;
@@ -1532,31 +1542,60 @@ DEV void adam_kernel_end(const mopoe_buffers& buf, const AdamSegs& s, bool valid
     }
 }
 
+// k_adam: a block's operands are requested FIRST (they are on their way while one thread
+// fetches the step's coefficients and the validity words in ONE round trip of independent
+// loads), the next step's records are made by block (0, 0) under the others' streaming.
 __global__ __launch_bounds__(256) void k_adam(const mopoe_buffers buf, const AdamSegs s) {
     __shared__ AdamCoef sc;
     __shared__ int ok;
-    if (threadIdx.x == 0) {
-        sc = adam_coef_load(buf.counters, s.seg_mod[blockIdx.y], s.adam);
-        ok = adam_step_valid(buf, s, buf.grads + s.off_ctrl);
+    const int seg = blockIdx.y, tid = threadIdx.x;
+    const int beg = s.begin[seg], end = s.end[seg];   // (beg: 256-byte aligned)
+    const int wsrc = s.wf_src[seg], wcnt = s.wf_count[seg], wk = s.wf_k[seg];
+    const int wk4 = s.wf_k4[seg], wdst = s.wf_dst[seg];
+    const bool wcopy = buf.wfrag != nullptr && wsrc >= 0;
+    const size_t pbytes = (size_t)end * sizeof(float);
+    const rsrc_t rp = make_rsrc(buf.params, pbytes), rm = make_rsrc(buf.exp_avg, pbytes);
+    const rsrc_t rv = make_rsrc(buf.exp_avg_sq, pbytes), rg = make_rsrc(buf.grads, pbytes);
+    const rsrc_t rf = make_rsrc(buf.wfrag, wcopy ? (size_t)s.wf_total * sizeof(float) : 0);
+    // four consecutive floats per thread (16-byte accesses; the words a load takes past
+    // `end` come back as zeros and are not stored)
+    const int stride = 4 * gridDim.x * blockDim.x;
+    int i = beg + 4 * (blockIdx.x * blockDim.x + tid);
+    f32x4 g4, p4, m4, v4;
+    auto request = [&](int at) __attribute__((always_inline)) {
+        const uint32_t o = guard((uint32_t)at * 4u, at < end);
+        g4 = ldg4(rg, o);
+        p4 = ldg4(rp, o);
+        m4 = ldg4(rm, o);
+        v4 = ldg4(rv, o);
+    };
+    request(i);
+    if (tid == 0) {
+        const int mod = s.seg_mod[seg];
+        const AdamCoefRaw q = adam_coef_request(buf.counters, mod);
+        bool good = q.invalid == 0;
+        if (s.world > 1) {   // (independent loads: one round trip with the request above)
+            const float* ctrl = buf.grads + s.off_ctrl;
+            float cw[MOPOE_MAX_MODS + 1];
+#pragma unroll
+            for (int m = 0; m <= MOPOE_MAX_MODS; ++m) cw[m] = __builtin_nontemporal_load(ctrl + m);
+#pragma unroll
+            for (int m = 0; m < MOPOE_MAX_MODS; ++m)
+                if (m < s.num_mods) good &= cw[m] == ((s.present_mask >> m) & 1 ? (float)s.world : 0.f);
+            good &= cw[MOPOE_MAX_MODS] == 0.f;
+        }
+        AdamCoef c;
+        if (!adam_coef_resolve(q, s.adam, c) && q.invalid == 0)   // no record for this step: from the count
+            c = adam_coef_load(buf.counters, mod, s.adam);
+        sc = c;
+        ok = good;
     }
     __syncthreads();
     const AdamCoef ac = sc;
     const bool valid = ok != 0;
-    const int beg = s.begin[blockIdx.y], end = s.end[blockIdx.y];   // (beg: 256-byte aligned)
-    const int wsrc = s.wf_src[blockIdx.y], wcnt = s.wf_count[blockIdx.y], wk = s.wf_k[blockIdx.y];
-    const int wk4 = s.wf_k4[blockIdx.y], wdst = s.wf_dst[blockIdx.y];
-    const bool wcopy = buf.wfrag != nullptr && wsrc >= 0;
     if (valid) {
-        const size_t pbytes = (size_t)end * sizeof(float);
-        const rsrc_t rp = make_rsrc(buf.params, pbytes), rm = make_rsrc(buf.exp_avg, pbytes);
-        const rsrc_t rv = make_rsrc(buf.exp_avg_sq, pbytes), rg = make_rsrc(buf.grads, pbytes);
-        const rsrc_t rf = make_rsrc(buf.wfrag, wcopy ? (size_t)s.wf_total * sizeof(float) : 0);
-        // four consecutive floats per thread (16-byte accesses; the words a load takes past
-        // `end` come back as zeros and are not stored)
-        for (int i = beg + 4 * (blockIdx.x * blockDim.x + threadIdx.x); i < end;
-             i += 4 * gridDim.x * blockDim.x) {
+        for (; i < end; i += stride) {
             const uint32_t o = (uint32_t)i * 4u;
-            const f32x4 g4 = ldg4(rg, o), p4 = ldg4(rp, o), m4 = ldg4(rm, o), v4 = ldg4(rv, o);
             f32x4 np, nm, nv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1595,9 +1634,17 @@ __global__ __launch_bounds__(256) void k_adam(const mopoe_buffers buf, const Ada
                     }
                 }
             }
+            if (i + stride < end) request(i + stride);
         }
     }
-    adam_kernel_end(buf, s, valid, gridDim.x * gridDim.y, threadIdx.x);
+    // the next step's records (slot (s + 1) & 1: nobody reads it during this step), by the
+    // first block, from the counts as they will stand once the last block has advanced them
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid < s.num_mods) {
+        const int step = buf.counters[MOPOE_CTR_STEPS_BEGUN];
+        const int t = buf.counters[MOPOE_CTR_ADAM_STEPS + tid] + ((valid && ((s.present_mask >> tid) & 1)) ? 1 : 0);
+        *bias_rec(buf.counters, step + 1, tid) = bias_of(s.adam, t + 1, step + 1);
+    }
+    adam_kernel_end(buf, s, valid, gridDim.x * gridDim.y, tid, false);
 }
 
 // ---------------------------------------------------------------------------
