@@ -211,6 +211,7 @@ struct LatentLds {
     int fits;                          // the carve-up fits the 160 KiB budget
 };
 
+
 // Carve-up for groups of R rows (every tile R rows tall); returns false when even the
 // most frugal option does not fit the 160 KiB budget.
 HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int waves, int R,

@@ -2137,11 +2137,7 @@ int launch_form(const KArgs& ka) {
         if (st.sub_kind[k] == MOPOE_SUB_SLICES) return 0;
     if (mdl.num_mods <= 2 && L.single_pass && L.s3_nt == 2 && L.xs_early && st.num_jobs <= 2) return 1;
     if (mdl.num_mods <= 2 && !L.single_pass && L.s3_nt == 2 && L.xs_early && st.num_jobs <= 4) return 2;
-    // (form 3 parks two values per (subset, content element) of its fusion backward in the x
-    //  tiles' LDS area, [0, gzp): they must fit)
-    if (mdl.num_mods <= 4 && L.single_pass && L.s3_nt == 4 && !L.xs_early && st.num_jobs <= 4 &&
-        2 * st.num_subsets * L.rd <= L.gzp)
-        return 3;
+    if (mdl.num_mods <= 4 && L.single_pass && L.s3_nt == 4 && !L.xs_early && st.num_jobs <= 4) return 3;
     return 0;
 }
 

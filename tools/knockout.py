@@ -31,6 +31,7 @@ PHASES = ["wait for the producers", "noise", "x tiles", "h -> LDS", "S1 heads MF
 
 def run(mask):
     os.environ["MOPOE_KNOCK"] = str(mask)
+    mm._lib.reload_knobs()          # (the library reads its environment once)
     eng = mm.MoPoEEngine(spec, "cuda", seed=1)
     eng.check_valid = lambda sync=False: None
     for i in range(200):

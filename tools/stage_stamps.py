@@ -15,11 +15,18 @@ import mopoe_amd as mm  # noqa: E402
 
 method = sys.argv[1] if len(sys.argv) > 1 else "joint_elbo"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-spec = mm.ModelSpec(["clinical", "rois"], [7, 444], [3, 20], method=method)
+if method in ("C1", "C3", "C5"):        # bench.py's configurations
+    import bench
+    cfg = bench.CONFIGS[method]
+    spec = bench.make_spec(cfg)
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else cfg["batch"]
+    names_, dims_ = cfg["names"], cfg["dims"]
+else:
+    spec = mm.ModelSpec(["clinical", "rois"], [7, 444], [3, 20], method=method)
+    names_, dims_ = ["clinical", "rois"], [7, 444]
 eng = mm.MoPoEEngine(spec, "cuda", seed=1)
 g = torch.Generator().manual_seed(0)
-pool = [{"clinical": torch.randn(n, 7, generator=g).cuda(),
-         "rois": torch.randn(n, 444, generator=g).cuda()} for _ in range(8)]
+pool = [{k: torch.randn(n, d, generator=g).cuda() for k, d in zip(names_, dims_)} for _ in range(8)]
 names = ["S0 h->LDS", "S1 heads", "S2a combine + x->LDS", "S2b fusion fwd",
          "S3 decoder+NLL (+KL sums)", "S4 g_z partials", "S4b (poe only)", "S5 fusion bwd",
          "S6 g_pre", "tail"]
@@ -55,3 +62,4 @@ if os.environ.get("MOPOE_QUAD") == "1":
           "to the barrier's end %.2f us" % tuple(inner4[:, 0] / 100.0))
 print("inside S3 (wave 8): loads+MFMA issue %.2f | four rows of epilogue %.2f | sums %.2f | "
       "waiting at the barrier %.2f us" % tuple(inner[:, 0] / 100.0))
+
