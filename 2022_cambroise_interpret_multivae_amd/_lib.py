@@ -123,6 +123,7 @@ class Buffers(C.Structure):
         ("g_pre", _ptr * MAX_MODS),
         ("wfrag", _ptr),
         ("partials", _ptr),
+        ("wgrad_scratch", _ptr),
     ]
 
 
@@ -174,6 +175,7 @@ SYMBOLS = {
     "mopoe_model_layout": (C.c_int, [C.POINTER(Model)]),
     "mopoe_ldz": (C.c_int, [C.POINTER(Model), C.c_int]),
     "mopoe_partials_stride": (C.c_int, [C.POINTER(Model)]),
+    "mopoe_wgrad_scratch_floats": (C.c_int64, [C.POINTER(Model), C.POINTER(Step)]),
     "mopoe_wfrag_floats": (C.c_int, [C.POINTER(Model)]),
     "mopoe_wfrag_refresh": (C.c_int, [C.POINTER(Model), C.POINTER(Buffers), C.c_void_p]),
     "mopoe_row_groups": (C.c_int, [C.POINTER(Model), C.POINTER(Step)]),

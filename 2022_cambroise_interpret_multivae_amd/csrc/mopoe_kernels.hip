@@ -2335,6 +2335,8 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w, const XgPeer
     if (xg) w.xg = *xg;
 }
 
+#include "mopoe_wgrad_big.inc"
+
 bool default_topology(const mopoe_topology* tp);
 
 // `tp`: the model's topology (nullptr / the default one: the layout of mopoe_model_layout).
@@ -2403,6 +2405,7 @@ void comm_next(mopoe_comm* c, XgPeers& x);
 int comm_flag_stride(const mopoe_comm* c);
 int comm_check(const mopoe_comm* c, const mopoe_model* mdl);
 int comm_world(const mopoe_comm* c);
+int launch_wfrag(const mopoe_model& mdl, const mopoe_buffers& buf, hipStream_t s);
 
 // k_adam on the flat buffers with the gradient scaled by 1 / world.  `ctrl_check`: the
 // gradient buffer went through an all-reduce that also summed its control words (the ranks'
@@ -2455,6 +2458,25 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
     if (comm && (int)grid.x > comm_flag_stride(comm))   // one arrival flag per exchanging workgroup
         return fail(MOPOE_ERR_ARG, "more weight-gradient blocks than the communicator has flags%s");
     if (int rc = launch_forward_part(ka, adam, s)) return rc;
+    if (!comm && wgrad_big_step(ka.st) && buf->wgrad_scratch) {
+        // a large batch: 64 x 64 tiles over slices of the batch rows, the parts added in order
+        // by a second launch (+ Adam), then the launch's tail alone -- decoder-logvar blocks,
+        // the step's scalars and bookkeeping (mopoe_wgrad_big.inc)
+        WbArgs wb;
+        build_wbargs(ka, (comm || !fuse_adam) ? nullptr : adam, wb);
+        wb.scratch = buf->wgrad_scratch;
+        {
+            ProfScope ps(MOPOE_KERNEL_WGRAD, s);
+            hipLaunchKernelGGL(k_wgrad_big, dim3(wb.total_blocks), dim3(256), 0, s, wb);
+            hipLaunchKernelGGL(k_wgrad_big_reduce, dim3(wb.total_tiles), dim3(256), 0, s, ka.buf, wb);
+            w.total_tiles = 0;
+            w.njobs = 0;
+            hipLaunchKernelGGL((k_wgrad<8, false>), dim3(w.lvo_blocks + 1), dim3(512), 0, s, ka, w);
+        }
+        if (int rc = check_launch("k_wgrad_big")) return rc;
+        if (buf->wfrag && wb.fuse_adam) return launch_wfrag(*mdl, *buf, s);   // (the copies follow)
+        return 0;
+    }
     if (comm) {
         comm_next(comm, w.xg);
         w.xg.mask = ka.st.present_mask;
@@ -2655,6 +2677,15 @@ int mopoe_sizeof(int which) {
 int mopoe_ldz(const mopoe_model* mdl, int mod) { return ldz_glb(*mdl, mod); }
 
 int mopoe_partials_stride(const mopoe_model* mdl) { return partials_stride(*mdl); }
+int64_t mopoe_wgrad_scratch_floats(const mopoe_model* mdl, const mopoe_step* st) {
+    if (!mdl || !st || st->n < 1 || !wgrad_big_step(*st)) return 0;
+    KArgs ka;
+    memset(&ka, 0, sizeof(ka));
+    ka.mdl = *mdl;
+    ka.st = *st;
+    WbArgs wb;
+    return build_wbargs(ka, nullptr, wb);
+}
 int mopoe_wfrag_floats(const mopoe_model* mdl) { return mdl ? wfrag_layout(*mdl).total : 0; }
 int mopoe_row_groups(const mopoe_model* mdl, const mopoe_step* st) {
     if (!mdl || !st || st->n < 1) return 0;

@@ -78,6 +78,7 @@ class Workspace:
         self._stride = L.lib.mopoe_partials_stride(spec.c_model)
         self.partials = torch.zeros((n + L.ROWS - 1) // L.ROWS, self._stride, **f)
         self.backward = backward
+        self.wgrad_scratch = None   # partial weight-gradient tiles of a large batch (train_step)
         self._cbuf = self._cbuf_partials = None   # the engine's cached mopoe_buffers
         if backward:
             self.g_xhat = [torch.empty(slots * n, spec.input_dim[m], **f)
@@ -376,6 +377,7 @@ class MoPoEEngine:
             b.joint_logvar = L.ptr(ws.joint_logvar)
             b.stats = L.ptr(ws.stats)
             b.partials = L.ptr(ws.partials)
+            b.wgrad_scratch = L.ptr(ws.wgrad_scratch) if torch.is_tensor(ws.wgrad_scratch) else None
             self._optim_buffers(b)
             ws._cbuf, ws._cbuf_partials = b, ws.partials
         elif self._on_gpu and self.params._version != self._wfrag_version:
@@ -514,6 +516,11 @@ class MoPoEEngine:
         ws = self.workspace(n, slots, True, eb=eb)
         keep = self._bind_noise(plan, step, eps)
         step.seed = self.seed
+        if ws.wgrad_scratch is None and not self.spec.general:
+            # a large batch: scratch for the split weight-gradient launches (csrc/mopoe_wgrad_big.inc)
+            need = L.lib.mopoe_wgrad_scratch_floats(self.spec.c_model, step)
+            ws.wgrad_scratch = torch.empty(need, **ws._f) if need else False
+            ws._cbuf = None
         buf = self._buffers(ws, x, row_index, stats_host, plan=plan)
         adam = C.byref(self.adam) if apply_adam else None
         if self.spec.general:

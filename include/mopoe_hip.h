@@ -263,6 +263,12 @@ typedef struct mopoe_buffers {
                                             slab is the row group's hand-off flag
                                             in the fused launch, left at zero by
                                             every call that completes             */
+    float* wgrad_scratch;                /* optional, mopoe_wgrad_scratch_floats(model,
+                                            step) floats: partial 64 x 64 blocks of the
+                                            weight gradients of a LARGE batch (the batch
+                                            axis is split over workgroups, a second launch
+                                            adds the parts in a fixed order); NULL, or a
+                                            step whose count is 0: the one-launch form   */
 } mopoe_buffers;
 
 typedef struct mopoe_adam {
@@ -305,6 +311,9 @@ int mopoe_ldz(const mopoe_model* model, int mod);
 int mopoe_wfrag_floats(const mopoe_model* model);
 /* rebuild buffers.wfrag from buffers.params (see mopoe_buffers.wfrag) */
 int mopoe_wfrag_refresh(const mopoe_model* model, const mopoe_buffers* buf, void* stream);
+/* floats of mopoe_buffers.wgrad_scratch this training step would use (0: a batch
+ * below the size from which the split weight-gradient launches pay) */
+int64_t mopoe_wgrad_scratch_floats(const mopoe_model* model, const mopoe_step* step);
 /* floats per row group in `partials` */
 int mopoe_partials_stride(const mopoe_model* model);
 /* row groups the fused per-sample kernel cuts the batch into for this step

@@ -1,0 +1,85 @@
+"""GPU: the weight gradients of a LARGE batch (>= 4,096 rows: 64 x 64 tiles over slices of
+the batch rows + an ordered second launch, csrc/mopoe_wgrad_big.inc) against the oracle and
+against the one-launch form -- ragged row counts, gathered inputs, method poe's doubled
+decoder rows, four modalities, a frozen decoder scale."""
+from collections import OrderedDict
+
+import pytest
+import torch
+
+import mopoe_amd as mm
+import mopoe_oracle as mo
+from hip_util import Report, TOL, compare_forward, make_engine
+
+pytestmark = pytest.mark.gpu
+L = mm._lib
+C1 = dict(names=["clinical", "rois"], input_dim=[7, 444], style_dim=[3, 20])
+C5 = dict(names=["clinical", "rois", "snps", "tracts"], input_dim=[7, 444, 128, 64], style_dim=[3, 3, 3, 3])
+
+
+@pytest.mark.parametrize("base,method,n,extra", [
+    (C1, "joint_elbo", 4096 + 37, {}), (C1, "poe", 4100, {}), (C5, "joint_elbo", 4096, {}),
+    (C1, "moe", 5000, dict(learn_output_scale=False, factorized=False))],
+    ids=["c1_ragged", "c1_poe", "c5", "c1_moe_frozen_scale"])
+def test_large_batch_step_matches_oracle(base, method, n, extra):
+    cfg = mo.Config(method=method, **base, **extra)
+    spec, eng = make_engine(cfg)
+    params = mo.init_params(cfg, 0)
+    state = mo.adam_init(params)
+    x = mo.make_inputs(cfg.names, cfg.input_dim, n, seed=3)
+    noise = mo.Noise(generator=mo.noise_rng(4))
+    out, grads = mo.train_step(params, cfg, x, noise, state)
+    plan, ws = eng.train_step(x, eps=noise.tape)
+    torch.cuda.synchronize()
+    eng.check_valid(sync=True)
+    assert torch.is_tensor(ws.wgrad_scratch) and ws.wgrad_scratch.numel() == \
+        L.lib.mopoe_wgrad_scratch_floats(spec.c_model, plan.c_step) > 0      # (the form under test ran)
+    rep = Report("large batch %s n=%d" % (method, n))
+    compare_forward(rep, spec, eng, plan, ws, out, check_scale=False)
+    for k, g in grads.items():
+        rep.close_scaled("grad/" + k, eng.grad_views[k], g, TOL["grad"])
+        rep.close_scaled("exp_avg/" + k, spec.param_views(eng.exp_avg)[k], state["exp_avg"][k], TOL["grad"])
+        rep.close_scaled("exp_avg_sq/" + k, spec.param_views(eng.exp_avg_sq)[k],
+                         state["exp_avg_sq"][k], TOL["moment2"])
+    for k in set(params) - set(grads):           # a frozen parameter stays put
+        assert torch.equal(eng.named_params()[k].cpu(), mo.init_params(cfg, 0)[k]), k
+    rep.finish()
+
+
+def test_split_form_agrees_with_the_one_launch_form_and_keeps_the_weight_copies():
+    """Same gradients up to the summation order (gathered rows included), the fragment-major
+    weight copies follow the update, and a following small batch runs the four-row form on
+    them."""
+    cfg = mo.Config(**C1)
+    _, a = make_engine(cfg)
+    _, b = make_engine(cfg)
+    n = 8192
+    pool = mo.make_inputs(cfg.names, cfg.input_dim, 9000, seed=5)
+    idx = torch.randperm(9000, generator=torch.Generator().manual_seed(1))[:n].to(torch.int32)
+    eps = mo.Noise(generator=mo.noise_rng(6))
+    mo.forward(mo.init_params(cfg, 0), cfg, OrderedDict((k, v[idx.long()]) for k, v in pool.items()), eps)
+    xa = {k: v.cuda() for k, v in pool.items()}
+    _, wa = a.train_step(xa, eps=eps.tape, row_index=idx.cuda())
+    torch.cuda.synchronize()
+    wb = b.workspace(n, 1, True)
+    wb.wgrad_scratch = False                      # (the one-launch form)
+    b.train_step(xa, eps=eps.tape, row_index=idx.cuda())
+    torch.cuda.synchronize()
+    assert torch.is_tensor(wa.wgrad_scratch) and wb.wgrad_scratch is False
+    scale = b.grads.abs().max().item()
+    assert (a.grads - b.grads).abs().max().item() < 2e-6 * scale
+    assert torch.equal(wa.stats, wb.stats)        # (the forward and the scalars are the same launches)
+    ref = a.wfrag.clone()
+    a.refresh_wfrag()
+    torch.cuda.synchronize()
+    assert torch.equal(ref, a.wfrag)
+    small = mo.make_inputs(cfg.names, cfg.input_dim, 256, seed=7)
+    e2 = mo.Noise(generator=mo.noise_rng(8))
+    params = OrderedDict((k, v.cpu().clone()) for k, v in a.named_params().items())
+    out, grads = mo.loss_and_grads(params, cfg, small, e2)
+    a.train_step(small, eps=e2.tape, apply_adam=False)
+    torch.cuda.synchronize()
+    rep = Report("four-row form after a large batch")
+    for k, g in grads.items():
+        rep.close_scaled("grad/" + k, a.grad_views[k], g, TOL["grad"])
+    rep.finish()
