@@ -2467,7 +2467,7 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
         wb.scratch = buf->wgrad_scratch;
         {
             ProfScope ps(MOPOE_KERNEL_WGRAD, s);
-            hipLaunchKernelGGL(k_wgrad_big, dim3(wb.total_blocks), dim3(256), 0, s, wb);
+            hipLaunchKernelGGL(k_wgrad_big, dim3(round_up(wb.total_blocks, 8)), dim3(256), 0, s, wb);
             hipLaunchKernelGGL(k_wgrad_big_reduce, dim3(wb.total_tiles), dim3(256), 0, s, ka.buf, wb);
             w.total_tiles = 0;
             w.njobs = 0;

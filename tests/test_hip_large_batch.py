@@ -21,9 +21,13 @@ C5 = dict(names=["clinical", "rois", "snps", "tracts"], input_dim=[7, 444, 128, 
     (C1, "joint_elbo", 4096 + 37, {}), (C1, "poe", 4100, {}), (C5, "joint_elbo", 4096, {}),
     (C1, "moe", 5000, dict(learn_output_scale=False, factorized=False))],
     ids=["c1_ragged", "c1_poe", "c5", "c1_moe_frozen_scale"])
-def test_large_batch_step_matches_oracle(base, method, n, extra):
+@pytest.mark.parametrize("form", ["split", "one_launch"])
+def test_large_batch_step_matches_oracle(base, method, n, extra, form):
     cfg = mo.Config(method=method, **base, **extra)
     spec, eng = make_engine(cfg)
+    if form == "one_launch":        # (k_wgrad at the same size: the form the split one replaces)
+        slots = 2 if method == "poe" else 1
+        eng.workspace(n, slots, True).wgrad_scratch = False
     params = mo.init_params(cfg, 0)
     state = mo.adam_init(params)
     x = mo.make_inputs(cfg.names, cfg.input_dim, n, seed=3)
@@ -32,15 +36,35 @@ def test_large_batch_step_matches_oracle(base, method, n, extra):
     plan, ws = eng.train_step(x, eps=noise.tape)
     torch.cuda.synchronize()
     eng.check_valid(sync=True)
-    assert torch.is_tensor(ws.wgrad_scratch) and ws.wgrad_scratch.numel() == \
-        L.lib.mopoe_wgrad_scratch_floats(spec.c_model, plan.c_step) > 0      # (the form under test ran)
+    if form == "split":
+        assert torch.is_tensor(ws.wgrad_scratch) and ws.wgrad_scratch.numel() == \
+            L.lib.mopoe_wgrad_scratch_floats(spec.c_model, plan.c_step) > 0  # (the form under test ran)
+    else:
+        assert ws.wgrad_scratch is False
     rep = Report("large batch %s n=%d" % (method, n))
     compare_forward(rep, spec, eng, plan, ws, out, check_scale=False)
+    # With millions of pre-activations per step some land within rounding of ReLU's kink, and
+    # two float32 summation orders then disagree on [pre > 0] for that (row, unit): the whole
+    # gradient row of that hidden unit (first-layer weights + bias; nothing else depends on
+    # the first layer's mask) moves by a finite amount.  Such units -- |pre| < 3e-6 anywhere
+    # in the batch, from the oracle's float64 pre-activations -- are left out of the comparison.
+    init = mo.init_params(cfg, 0)
+    near_kink = {}
+    for name in x:
+        e = "encoders.%s.shared_encoder.0." % name
+        pre = x[name].double() @ init[e + "weight"].double().t() + init[e + "bias"].double()
+        near_kink[name] = (pre.abs() < 3e-6).any(0)
+    skipped = sum(int(v.sum()) for v in near_kink.values())
+    assert skipped <= 32, skipped
     for k, g in grads.items():
-        rep.close_scaled("grad/" + k, eng.grad_views[k], g, TOL["grad"])
-        rep.close_scaled("exp_avg/" + k, spec.param_views(eng.exp_avg)[k], state["exp_avg"][k], TOL["grad"])
-        rep.close_scaled("exp_avg_sq/" + k, spec.param_views(eng.exp_avg_sq)[k],
-                         state["exp_avg_sq"][k], TOL["moment2"])
+        keep = slice(None)
+        if ".shared_encoder.0." in k:
+            keep = ~near_kink[k.split(".")[1]]
+        rep.close_scaled("grad/" + k, eng.grad_views[k].cpu()[keep], g[keep], TOL["grad"])
+        rep.close_scaled("exp_avg/" + k, spec.param_views(eng.exp_avg)[k].cpu()[keep],
+                         state["exp_avg"][k][keep], TOL["grad"])
+        rep.close_scaled("exp_avg_sq/" + k, spec.param_views(eng.exp_avg_sq)[k].cpu()[keep],
+                         state["exp_avg_sq"][k][keep], TOL["moment2"])
     for k in set(params) - set(grads):           # a frozen parameter stays put
         assert torch.equal(eng.named_params()[k].cpu(), mo.init_params(cfg, 0)[k]), k
     rep.finish()
