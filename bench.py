@@ -48,6 +48,14 @@ import os
 import sys
 import time
 
+# The host waits for the GPU by polling instead of sleeping until an interrupt (ROCm's
+# HSA_ENABLE_INTERRUPT=0; it must be set before the runtime starts): a synchronisation then
+# costs ~5 us instead of 20-60.  A training run hardly ever synchronises, but the driver's
+# timed region is 20 steps = 0.6 ms between two of them: with interrupts its own brackets
+# were 3-5 us of every step it reported (35-39 us against 31.8-33.4 on the same box, the
+# 3,000-step figure 30.1 either way).  Reported as config.host_wait.
+os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -686,6 +694,8 @@ def main():
                                         "torch.distributed all_reduce (RCCL), adam_step"
                                 }[exchange] + (" [%s]" % why if why else ""),
                    "host_log_every_step": not args.no_log_copy,
+                   "host_wait": "polling (HSA_ENABLE_INTERRUPT=0)"
+                                if os.environ.get("HSA_ENABLE_INTERRUPT") == "0" else "interrupts",
                    "settle_steps": SETTLE,
                    # `value` is the SECOND timing of the same W + K steps: what ran before it
                    "warmup_effective": 2 * args.warmup + args.steps + SETTLE,
