@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "mopoe_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(mopoe_[a-z0-9_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(mopoe_[a-z0-9_]+)\s*\(", header, re.M))
     assert declared, "no declarations parsed"
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
     for name in declared:
