@@ -84,6 +84,11 @@ CONFIGS = {
                style=[3, 3, 3, 3], method="joint_elbo", batch=512,
                label="configs[4]: 4 modalities (7,444,128,64), joint_elbo over the 15-subset "
                      "powerset, batch 512 on one GPU"),
+    # SURVEY section 8d's second regime: configs[1]'s model where the batch term dominates
+    # (profiling only: tools/profile_round.sh <tag> --config N64K)
+    "N64K": dict(names=["clinical", "rois"], dims=[7, 444], style=[3, 20], method="joint_elbo",
+                 batch=65536, label="configs[1]'s model at 65,536 rows per step (the MFMA / "
+                                    "bandwidth regime; not a BASELINE configuration)"),
 }
 LATENT = 20
 
@@ -547,7 +552,7 @@ def main():
     spec = make_spec(c)
     eng = mm.MoPoEEngine(spec, device, seed=1234)
     eng.reset_parameters(torch.Generator().manual_seed(0))  # same on all ranks
-    pool = make_pool(c, device)
+    pool = make_pool(c, device, count=min(POOL, max(2, (1 << 28) // (4 * BATCH * sum(c["dims"])))))
     log_ring = [torch.empty(mm._lib.NUM_STATS, dtype=torch.float32).pin_memory()
                 for _ in range(8)]
     fused = dist is None
@@ -564,7 +569,7 @@ def main():
                 sys.exit("MOPOE_EXCHANGE=xgmi but: " + why)
             exchange = "xgmi" if comm is not None else "rccl"
         if comm is not None and os.environ.get("MOPOE_EXCHANGE_AFTER") is None:
-            in_backward = check_in_backward(comm, spec, pool[rank % POOL], device, world, dist)
+            in_backward = check_in_backward(comm, spec, pool[rank % len(pool)], device, world, dist)
             if not in_backward:
                 why = "exchange inside the weight-gradient launch failed its start-up check"
         # replicas start identical (parameters, moments, step counts)
@@ -578,12 +583,12 @@ def main():
         # the step's scalar log lands in a ring of pinned host buffers, written
         # by the kernel itself (no copy on the stream)
         if comm is not None and in_backward:
-            return eng.train_step(pool[(i * world + rank) % POOL], apply_adam=True, comm=comm,
+            return eng.train_step(pool[(i * world + rank) % len(pool)], apply_adam=True, comm=comm,
                                   stats_host=None if args.no_log_copy else log_ring[i % 8])[1]
         if rccl is not None:        # ONE host call: backward, ncclAllReduce, Adam
-            return eng.train_step(pool[(i * world + rank) % POOL], apply_adam=True, rccl=rccl,
+            return eng.train_step(pool[(i * world + rank) % len(pool)], apply_adam=True, rccl=rccl,
                                   stats_host=None if args.no_log_copy else log_ring[i % 8])[1]
-        plan, ws = eng.train_step(pool[(i * world + rank) % POOL], apply_adam=fused,
+        plan, ws = eng.train_step(pool[(i * world + rank) % len(pool)], apply_adam=fused,
                                   stats_host=None if args.no_log_copy else log_ring[i % 8])
         if comm is not None:
             comm.allreduce_adam(eng)                # one launch: push, sum, Adam

@@ -13,6 +13,10 @@ import os
 import sys
 
 
+KERNELS = ("k_linear_big", "k_linear", "k_latent", "k_wgrad_big_reduce", "k_wgrad_big", "k_wgrad",
+           "k_adam", "k_finalize", "k_fused", "k_wfrag", "k_xgmi")
+
+
 def per_kernel(path, counter):
     tot, cnt = {}, {}
     for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
@@ -21,9 +25,7 @@ def per_kernel(path, counter):
                 if row["Counter_Name"] != counter:
                     continue
                 name = row["Kernel_Name"]
-                short = next((k for k in ("k_linear", "k_latent", "k_wgrad", "k_adam",
-                                          "k_finalize", "k_fused") if k + "(" in name or k + "<" in name),
-                             None)
+                short = next((k for k in KERNELS if k + "(" in name or k + "<" in name), None)
                 if short is None:
                     continue
                 tot[short] = tot.get(short, 0.0) + float(row["Counter_Value"])
