@@ -205,6 +205,7 @@ struct LatentLds {
     int wd_units[2];                             // 1 KB units (64 pieces of 16 bytes) of it, per present modality
     int wd_valid[2];                             // pieces that hold weights (the rest: zero rows)
     int quad_ok;
+    int fold_tiles;                    // > 0: `partials` holds this many pre-summed slabs (large batches: k_partials_fold)
     WFrag wf;                                    // fragment-major weight copies (mopoe_buffers.wfrag)
     int rows;                          // batch rows a group owns (16, 8, 4, 2 or 1)
     int rd;                            // round_up(rows * class_dim, 4): stride of a KL-term slab

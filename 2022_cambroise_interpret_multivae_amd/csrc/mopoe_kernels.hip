@@ -882,7 +882,7 @@ DEV void finalize_stats(const KArgs& a, int tid) {
     __shared__ float jdc[MOPOE_MAX_SUBSETS];
     const mopoe_buffers& buf = a.buf;
     const mopoe_step& st = a.st;
-    const int tiles = cdiv(st.n, a.lds.rows);
+    const int tiles = a.lds.fold_tiles > 0 ? a.lds.fold_tiles : cdiv(st.n, a.lds.rows);
     const int stride = a.lds.part_stride;
     if (tid < SLICES * kStatStride) {
         // partial index p = tid % kStatStride, tile slice = tid / kStatStride; slices
@@ -1345,7 +1345,7 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
     const int lb = b - w.total_tiles;
     if (lb < w.lvo_blocks) {
         GSTAMP(buf.stats, kStampBase + 62, lb == w.lvo_blocks - 1 && tid == 0);
-        const int tiles = cdiv(a.st.n, a.lds.rows);
+        const int tiles = a.lds.fold_tiles > 0 ? a.lds.fold_tiles : cdiv(a.st.n, a.lds.rows);
         const int stride = a.lds.part_stride;
         // d loss / d decoders.<m>.logvar: sum of the row groups' partials.  A block
         // owns 64 columns; its waves take an equal share of the groups each (sixteen
@@ -2067,6 +2067,7 @@ bool quad_tables(const mopoe_model& mdl, const mopoe_step& st, LatentLds& L) {
 
 void step_layout(const mopoe_model& mdl, const mopoe_step& st, LatentLds& L) {
     L.quad_ok = 0;
+    L.fold_tiles = 0;
     if (quad_step(mdl, st)) {
         L.fits = latent_lds_layout_rows(mdl, st, kLatentWaves, 4, L);
         if (L.fits && L.xs_early && L.s3_nt == 2 && quad_tables(mdl, st, L)) {
@@ -2271,14 +2272,23 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
 
     static thread_local int lds_opted = 0;
     if (lds > 64 * 1024 && lds > lds_opted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_latent),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail(MOPOE_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        const void* forms[] = {reinterpret_cast<const void*>(k_latent<0>), reinterpret_cast<const void*>(k_latent<1>),
+                               reinterpret_cast<const void*>(k_latent<2>), reinterpret_cast<const void*>(k_latent<3>)};
+        for (const void* fn : forms) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return fail(MOPOE_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
         lds_opted = lds;
     }
     {
         ProfScope ps(MOPOE_KERNEL_LATENT, s);
-        hipLaunchKernelGGL(k_latent, dim3(cdiv(ka.st.n, ka.lds.rows)), dim3(kLatentThreads), (size_t)lds, s, ka);
+        const dim3 grid(cdiv(ka.st.n, ka.lds.rows)), block(kLatentThreads);
+        switch (launch_form(ka)) {   // (the specialised bodies: training steps of the shapes that matter)
+            case 1: hipLaunchKernelGGL(k_latent<1>, grid, block, (size_t)lds, s, ka); break;
+            case 2: hipLaunchKernelGGL(k_latent<2>, grid, block, (size_t)lds, s, ka); break;
+            case 3: hipLaunchKernelGGL(k_latent<3>, grid, block, (size_t)lds, s, ka); break;
+            default: hipLaunchKernelGGL(k_latent<0>, grid, block, (size_t)lds, s, ka); break;
+        }
     }
     return check_launch("k_latent");
 }
@@ -2463,15 +2473,28 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
         // by a second launch (+ Adam), then the launch's tail alone -- decoder-logvar blocks,
         // the step's scalars and bookkeeping (mopoe_wgrad_big.inc)
         WbArgs wb;
-        build_wbargs(ka, (comm || !fuse_adam) ? nullptr : adam, wb);
+        const int64_t wb_floats = build_wbargs(ka, (comm || !fuse_adam) ? nullptr : adam, wb);
         wb.scratch = buf->wgrad_scratch;
+        // the row groups' partial slabs (thousands of them) are summed in kFoldSlices slices by
+        // a launch of their own; the tail's few blocks then add kFoldSlices slabs instead of
+        // walking all of them (65,536 rows: 47 -> ~10 us)
+        KArgs kt = ka;
+        const int groups = cdiv(ka.st.n, ka.lds.rows);
+        const bool fold = groups >= 4 * kFoldSlices;
+        if (fold) {
+            kt.buf.partials = buf->wgrad_scratch + wb_floats;
+            kt.lds.fold_tiles = kFoldSlices;
+        }
         {
             ProfScope ps(MOPOE_KERNEL_WGRAD, s);
             hipLaunchKernelGGL(k_wgrad_big, dim3(round_up(wb.total_blocks, 8)), dim3(256), 0, s, wb);
-            hipLaunchKernelGGL(k_wgrad_big_reduce, dim3(wb.total_tiles), dim3(256), 0, s, ka.buf, wb);
+            hipLaunchKernelGGL(k_wgrad_big_reduce, dim3(wb.total_tiles * kWbReduceParts), dim3(256), 0, s, ka.buf, wb);
+            if (fold)
+                hipLaunchKernelGGL(k_partials_fold, dim3(cdiv(ka.lds.part_stride, 256), kFoldSlices), dim3(256), 0, s,
+                                   (const float*)buf->partials, kt.buf.partials, groups, ka.lds.part_stride);
             w.total_tiles = 0;
             w.njobs = 0;
-            hipLaunchKernelGGL((k_wgrad<8, false>), dim3(w.lvo_blocks + 1), dim3(512), 0, s, ka, w);
+            hipLaunchKernelGGL((k_wgrad<8, false>), dim3(w.lvo_blocks + 1), dim3(512), 0, s, kt, w);
         }
         if (int rc = check_launch("k_wgrad_big")) return rc;
         if (buf->wfrag && wb.fuse_adam) return launch_wfrag(*mdl, *buf, s);   // (the copies follow)
@@ -2684,7 +2707,7 @@ int64_t mopoe_wgrad_scratch_floats(const mopoe_model* mdl, const mopoe_step* st)
     ka.mdl = *mdl;
     ka.st = *st;
     WbArgs wb;
-    return build_wbargs(ka, nullptr, wb);
+    return build_wbargs(ka, nullptr, wb) + (int64_t)kFoldSlices * partials_stride(*mdl);
 }
 int mopoe_wfrag_floats(const mopoe_model* mdl) { return mdl ? wfrag_layout(*mdl).total : 0; }
 int mopoe_row_groups(const mopoe_model* mdl, const mopoe_step* st) {

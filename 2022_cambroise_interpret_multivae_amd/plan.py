@@ -13,6 +13,7 @@ Paths are relative to the reference's experiments/ directory.
 from collections import OrderedDict
 from itertools import chain, combinations
 
+import os
 import torch
 
 from . import _lib as L
@@ -92,7 +93,8 @@ class ModelSpec:
         if not 0.0 <= self.dropout < 1.0:
             raise ValueError("dropout_rate must be in [0, 1)")
         self.general = (self.enc_layers, self.dec_layers, self.dropout,
-                        self.sample_scale) != (1, 0, 0.0, False)
+                        self.sample_scale) != (1, 0, 0.0, False) or \
+            os.environ.get("MOPOE_FORCE_GENERAL") == "1"   # (experiments: the chain on the default topology)
 
         c = L.Model()
         c.num_mods = M

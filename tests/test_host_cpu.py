@@ -196,7 +196,7 @@ def test_hot_kernels_keep_their_registers_and_scratch():
                              sgpr_spill=get("SGPRs Spill"), occupancy=get("Occupancy [waves/SIMD]"))
     pick = lambda frag: next(v for k, v in kernels.items() if frag in k)
     lean, generic = pick("k_fusedILi1EE"), pick("k_fusedILi0EE")
-    latent, linear = pick("k_latentE"), pick("8k_linearE")
+    latent, linear = pick("k_latentILi0EE"), pick("8k_linearE")
     # (measured builds of the lean launch: 24..80 bytes of scratch all ran within 1 % of each
     #  other; 112 bytes and more cost a microsecond)
     assert lean["vgpr"] <= 128 and lean["scratch"] <= 96 and lean["occupancy"] >= 4, lean
@@ -208,6 +208,8 @@ def test_hot_kernels_keep_their_registers_and_scratch():
     for frag in ("k_fusedILi2EE", "k_fusedILi3EE"):      # the poe / four-modality forms
         assert pick(frag)["vgpr"] <= 128 and pick(frag)["scratch"] <= 256, (frag, pick(frag))
     assert latent["vgpr"] <= 128 and latent["scratch"] == 0, latent
+    for frag in ("k_latentILi1EE", "k_latentILi2EE", "k_latentILi3EE"):   # large batches: the specialised bodies
+        assert pick(frag)["vgpr"] <= 128 and pick(frag)["scratch"] <= 64, (frag, pick(frag))
     assert linear["scratch"] == 0, linear
     for frag in ("k_wgradILi4ELb0", "k_wgradILi8ELb0", "k_wgradILi4ELb1", "k_wgradILi8ELb1",
                  "k_adamE", "k_xgmiE", "k_linear_bigE"):

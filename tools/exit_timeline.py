@@ -23,9 +23,9 @@ pool = [{k: torch.randn(cfg["batch"], d, generator=g).cuda() for k, d in zip(cfg
         for _ in range(16)]
 STEPS = int(os.environ.get("KNOCK_STEPS", "1000"))
 POINTS = [(12, "entry (argument prefetch issued)"), (0, "S0: requests out, LDS zeroed"),
-          (1, "S0 end: h in LDS"), (2, "S1 end: heads"), (3, "(x tiles, late form)"),
+          (1, "S0 end: h in LDS"), (13, "S1: K parts of the heads in LDS"), (2, "S1 end: heads"), (3, "(x tiles, late form)"),
           (4, "S2b end: fusion forward"), (6, "S3 end: decoder + NLL"), (7, "S4 end: dL/dz"),
-          (8, "decoder passes done"), (9, "S5 end: fusion backward"), (10, "S6 end: dL/dh"),
+          (8, "decoder passes done"), (9, "S5 end: fusion backward"), (14, "S6: K parts of dL/dh in LDS"), (10, "S6 end: dL/dh"),
           (11, "tail")]
 
 

@@ -46,6 +46,15 @@ def run(mask):
     return prof["k_fused"][1] / prof["k_fused"][0] * 1e3
 
 
+if os.environ.get("KNOCK_MASKS"):       # "label=mask;label=mask": just these, against the full launch
+    full = run(0)
+    print("k_fused, all phases: %.2f us" % full)
+    for item in os.environ["KNOCK_MASKS"].split(";"):
+        label, mask = item.rsplit("=", 1)
+        t = run(int(mask, 0))
+        print("  %-46s %6.2f us   (%+.2f)" % (label, t, t - full), flush=True)
+    print("k_fused, all phases again: %.2f us" % run(0))
+    sys.exit(0)
 full = run(0)
 print("k_fused, all phases (HIP events, incl. ~2 us of event overhead): %.2f us" % full)
 ONLY = [int(v) for v in os.environ.get("KNOCK_ONLY", "").split(",") if v]   # phase numbers
