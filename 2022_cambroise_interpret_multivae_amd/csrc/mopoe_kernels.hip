@@ -1899,7 +1899,11 @@ void bind_buffers(KArgs& ka, const mopoe_buffers& buf) {
 // kernels between two steps of one run.  mopoe_reload_knobs() re-reads them (the tests that
 // compare launch forms inside one process call it after changing the environment).
 struct Knobs {
-    int quad_max_n;      // MOPOE_QUAD_MAX_N: rows up to which the four-row form is used (256)
+    int quad_max_n;      // MOPOE_QUAD_MAX_N: rows up to which the four-row form is used (512; at most 1024:
+                         // one group per CU.  Measured, us per step, sixteen-row / four-row groups: joint_elbo
+                         // 384 rows 38.1 / 32.9, 512: 39.2 / 37.1, 640: 43.0 / 46.6, 768: 46.3 / 51.9,
+                         // 1024: 46.6 / 49.9; poe 512: 50.2 / 44.1, 1024: 58.3 / 57.6 -- from 640 rows on the
+                         // producers of the four-row grid are 256-column blocks, or a launch of their own)
     bool quad;           // MOPOE_QUAD=0 turns the four-row form off
     bool no_fuse;        // MOPOE_NO_FUSE: encoder layer and per-sample chain in two launches
     bool no_lean;        // MOPOE_NO_LEAN: the generic instantiation of the fused launch
@@ -1908,6 +1912,8 @@ struct Knobs {
     int fuse_blocks;     // MOPOE_FUSE_BLOCKS: largest grid the fused launch is used for (256)
     int knock;           // MOPOE_KNOCK (diagnostic build): phases to leave out
     bool wgrad_nofold, wgrad_tall;   // MOPOE_WGRAD_NOFOLD / MOPOE_WGRAD_TALL: experiments
+    int lin_ks;          // MOPOE_LIN_KS: K parts of the separate encoder-layer launch (0: its own choice; experiments)
+    int lin_big_rows;    // MOPOE_LIN_BIG_ROWS: rows from which the encoder layer runs in 64 x 64 tiles (kLinBigRows)
     int xg_fail_slot;    // MOPOE_TEST_XG_FAIL_SLOT: the exchanging block that reports a failed wait (-1)
 };
 Knobs read_knobs() {
@@ -1916,11 +1922,13 @@ Knobs read_knobs() {
         return v ? (int)strtol(v, nullptr, 0) : dflt;
     };
     Knobs k;
-    k.quad_max_n = num("MOPOE_QUAD_MAX_N", 256);
+    k.quad_max_n = num("MOPOE_QUAD_MAX_N", 512);
     k.quad = num("MOPOE_QUAD", 1) != 0;
     k.no_fuse = getenv("MOPOE_NO_FUSE") != nullptr;
     k.no_lean = getenv("MOPOE_NO_LEAN") != nullptr;
     k.q1_idle = num("MOPOE_Q1_IDLE", 2);
+    k.lin_big_rows = num("MOPOE_LIN_BIG_ROWS", kLinBigRows);
+    k.lin_ks = num("MOPOE_LIN_KS", 0);
     k.handoff_spins = num("MOPOE_TEST_HANDOFF_SPINS", kHandoffSpins);
     k.fuse_blocks = num("MOPOE_FUSE_BLOCKS", 256);
     k.knock = num("MOPOE_KNOCK", 0);
@@ -1941,6 +1949,7 @@ bool quad_step(const mopoe_model& mdl, const mopoe_step& st) {
     if (!g_knobs.quad) return false;
     if (!st.backward || !st.sample || st.joint_mode != MOPOE_JOINT_MIXTURE || st.group_rows != 0 ||
         st.rows_per_group != 0 || mdl.num_mods > 2 || st.num_jobs > 4 || st.n > quad_max_rows() || st.n < 4 ||
+        cdiv(st.n, 4) > g_knobs.fuse_blocks ||   // (every row group resident: one per CU)
         st.likelihood != MOPOE_LIK_NORMAL)
         return false;
     for (int k = 0; k < st.num_subsets; ++k)
@@ -2092,7 +2101,7 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s, 
     LinArgs la = la_in;
     const int kp = round_up(max_k < kEncKChunk ? max_k : kEncKChunk, 16);
     const size_t lds = ((size_t)kRows * (kp + 4) + kLinRedFloats) * sizeof(float);
-    if (la.n >= kLinBigRows) {
+    if (la.n >= g_knobs.lin_big_rows) {
         ProfScope ps(MOPOE_KERNEL_LINEAR, s);
         hipLaunchKernelGGL(k_linear_big,
                            dim3(cdiv(max_cols, kBigCols), cdiv(la.n, kBigRows), la.ngroups),
@@ -2104,6 +2113,7 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s, 
     int ks = 1;
     while (ks < 4 && tiles * cdiv(max_cols, 64 / ks) < 2 * 256) ks *= 2;
     if (ks_hint) ks = ks_hint;
+    if (g_knobs.lin_ks) ks = g_knobs.lin_ks;
     la.ksplit = ks;
     {
         ProfScope ps(MOPOE_KERNEL_LINEAR, s);
@@ -2233,6 +2243,20 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     la.sig_n = hd.gpt;
     la.sig_stride = ka.lds.part_stride;
     la.sig_groups = groups;
+    // Four-row groups whose producers would not fit the chip beside them (257..1024 rows): the
+    // encoder layer runs as a launch of its own and the fused launch is row groups only --
+    // all of them resident, one per CU, where sixteen-row groups would use a quarter of the CUs
+    const bool quad_split = quad && ka.st.group_rows == 0 && nlin + groups > fuse_blocks() &&
+                            groups <= fuse_blocks() && !no_fuse();
+    if (quad_split) {
+        if (int rc = launch_linear(la, maxd, kHid, s, 0)) return rc;   // (bumps the step counter, publishes Adam's records)
+        la.counters = nullptr;
+        la.publish = 0;
+        memset(hd.begin, 0, sizeof(hd.begin));
+        memset(blocks_per_tile, 0, sizeof(blocks_per_tile));
+        hd.producers = 0;
+        hd.nlin = nlin = 0;
+    }
     if ((ka.lds.rows == kRows || quad) && ka.st.group_rows == 0 && nlin + groups <= fuse_blocks() && !no_fuse()) {
         static thread_local int lds_opted_f = 0;
         const int kp = round_up(maxd < kEncKChunk ? maxd : kEncKChunk, 16);

@@ -12,9 +12,10 @@ import mopoe_amd as mm  # noqa: E402
 
 
 def run(method, n, env):
-    for k in ("MOPOE_QUAD", "MOPOE_QUAD_MAX_N", "MOPOE_FUSE_BLOCKS"):
+    for k in ("MOPOE_QUAD", "MOPOE_QUAD_MAX_N", "MOPOE_FUSE_BLOCKS", "MOPOE_LIN_BIG_ROWS", "MOPOE_LIN_KS"):
         os.environ.pop(k, None)
     os.environ.update(env)
+    mm._lib.reload_knobs()          # (the library reads its environment once)
     spec = mm.ModelSpec(["clinical", "rois"], [7, 444], [3, 20], method=method)
     eng = mm.MoPoEEngine(spec, "cuda", seed=1)
     g = torch.Generator().manual_seed(0)
@@ -44,11 +45,7 @@ def run(method, n, env):
 
 
 for rnd in range(2):
-    run("poe", 256, {"MOPOE_QUAD": "0"})
-    run("poe", 256, {})
-    run("poe", 1024, {})
-    run("poe", 1024, {"MOPOE_QUAD_MAX_N": "1024", "MOPOE_FUSE_BLOCKS": "512"})
-    run("joint_elbo", 512, {})
-    run("joint_elbo", 512, {"MOPOE_QUAD_MAX_N": "1024", "MOPOE_FUSE_BLOCKS": "512"})
-    run("joint_elbo", 1024, {})
-    run("joint_elbo", 1024, {"MOPOE_QUAD_MAX_N": "1024", "MOPOE_FUSE_BLOCKS": "512"})
+    for method, n in (("poe", 1024), ("joint_elbo", 768)):
+        run(method, n, {})                              # four-row groups, the encoder layer a launch of its own
+        run(method, n, {"MOPOE_LIN_KS": "2"})
+        run(method, n, {"MOPOE_LIN_KS": "4"})
