@@ -267,8 +267,10 @@ typedef struct mopoe_buffers {
                                             step) floats: partial 64 x 64 blocks of the
                                             weight gradients of a LARGE batch (the batch
                                             axis is split over workgroups, a second launch
-                                            adds the parts in a fixed order); NULL, or a
-                                            step whose count is 0: the one-launch form   */
+                                            adds the parts in a fixed order) and, behind
+                                            them, sixteen pre-summed slabs of `partials`;
+                                            NULL, or a step whose count is 0: the one-launch
+                                            form                                          */
 } mopoe_buffers;
 
 typedef struct mopoe_adam {
@@ -318,7 +320,8 @@ int64_t mopoe_wgrad_scratch_floats(const mopoe_model* model, const mopoe_step* s
 int mopoe_partials_stride(const mopoe_model* model);
 /* row groups the fused per-sample kernel cuts the batch into for this step
  * (= the number of partial slabs the caller provides): ceil(n / rows), rows = 16
- * unless the LDS carve-up asks for fewer or step->rows_per_group pins it */
+ * unless the LDS carve-up asks for fewer, step->rows_per_group pins it, or the step
+ * runs in four-row groups (training batches of 4..512 rows, <= 2 modalities) */
 int mopoe_row_groups(const mopoe_model* model, const mopoe_step* step);
 /* bytes of LDS the fused latent kernel needs for this model and step (<= 160 KiB
  * after the rows-per-group fallback; larger only if even one row does not fit) */
