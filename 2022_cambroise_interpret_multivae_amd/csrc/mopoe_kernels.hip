@@ -474,7 +474,13 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
 // MFMAs), and each of its four waves accumulates a 16 x 64 strip -> 16 flop per byte.
 // grid = (column groups of 64, row tiles of 64, groups), block = 256.
 // ---------------------------------------------------------------------------
-constexpr int kBigRows = 64, kBigCols = 64, kBigK = 64, kBigLd = kBigK + 4;
+#ifndef MOPOE_BIGK
+#define MOPOE_BIGK 32
+#endif
+constexpr int kBigRows = 64, kBigCols = 64, kBigK = MOPOE_BIGK, kBigLd = kBigK + 4;
+constexpr int kBigTpr = kBigK / 4;           // staging threads per row (a float4 each)
+constexpr int kBigRpp = 256 / kBigTpr;       // rows per staging pass
+constexpr int kBigPasses = kBigRows / kBigRpp;
 constexpr int kLinBigRows = 2048;  // batches from here on use it
 
 __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a_by_value) {
@@ -503,12 +509,12 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a_by_value) {
     const rsrc_t wr = make_rsrc(g.W, (size_t)g.ncols * K * sizeof(float));
     const bool vec = K % 4 == 0;
     // staging: thread -> 4 float4 of the x chunk and 4 of the W chunk (rows r0 + 16 i)
-    const int r0 = tid >> 4, k4 = (tid & 15) * 4;
-    f32x4 xa[4], wb[4];
+    const int r0 = tid / kBigTpr, k4 = (tid % kBigTpr) * 4;
+    f32x4 xa[kBigPasses], wb[kBigPasses];
     auto fetch = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = r0 + 16 * i, k = kc + k4;
+        for (int i = 0; i < kBigPasses; ++i) {
+            const int r = r0 + kBigRpp * i, k = kc + k4;
             const uint32_t xo = (uint32_t)(rowsel[r] * g.ldx + k) * 4u;
             const uint32_t wo = (uint32_t)((j0 + r) * K + k) * 4u;   // row >= ncols: out of range
             const bool rv = n0 + r < N;
@@ -526,8 +532,8 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a_by_value) {
     };
     auto park = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = r0 + 16 * i;
+        for (int i = 0; i < kBigPasses; ++i) {
+            const int r = r0 + kBigRpp * i;
             *reinterpret_cast<f32x4*>(&As[buf][r * kBigLd + k4]) = xa[i];
             *reinterpret_cast<f32x4*>(&Bs[buf][r * kBigLd + k4]) = wb[i];
         }

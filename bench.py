@@ -531,6 +531,12 @@ def main():
                          "Adam kernel) even with one rank")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line: whatever libraries print there while the run lasts (RCCL
+    # greets with a version banner on stdout when it sets up a communicator) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -577,7 +583,23 @@ def main():
             dist.broadcast(t, 0)
         eng.refresh_wfrag()      # (c10d writes do not bump tensor._version)
         if exchange == "rccl":
-            rccl = mm.comm.RcclComm()
+            # the library's own communicator; a set-up that fails (on every rank together) or
+            # an all-reduce that does not give c10d's sum leaves the spelled-out form
+            try:
+                rccl = mm.comm.RcclComm()
+                probe = torch.arange(4096, device=device, dtype=torch.float32) * (rank + 1)
+                want = probe.clone()
+                rccl.allreduce_(probe)
+                dist.all_reduce(want)
+                ok = torch.tensor([float(torch.equal(probe, want))], device=device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if not ok.item():
+                    rccl.close()
+                    rccl, why = None, "the library's RCCL all-reduce failed its start-up check"
+            except mm._lib.MopoeError as e:
+                rccl, why = None, "RCCL communicator: %s" % e
+            if rccl is None:
+                exchange = "c10d"
 
     def step(i):
         # the step's scalar log lands in a ring of pinned host buffers, written
@@ -652,6 +674,14 @@ def main():
             eng.exp_avg.zero_()
             eng.exp_avg_sq.zero_()
             dt, ws = measure()
+    replicas_identical = None
+    if dist is not None:
+        # (every form: the replicas must hold the same parameters after the timed region)
+        mine = eng.params.double().sum()
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(lo.item() == hi.item())
     if dist is not None:
         t = torch.tensor([dt, cold["dt"], cold["settle_dt"]], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -698,6 +728,7 @@ def main():
                                 "c10d": "three host calls per step: train_step, "
                                         "torch.distributed all_reduce (RCCL), adam_step"
                                 }[exchange] + (" [%s]" % why if why else ""),
+                   "replicas_identical_after_timed_region": replicas_identical,
                    "host_log_every_step": not args.no_log_copy,
                    "host_wait": "polling (HSA_ENABLE_INTERRUPT=0)"
                                 if os.environ.get("HSA_ENABLE_INTERRUPT") == "0" else "interrupts",
@@ -759,6 +790,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
 
