@@ -479,16 +479,22 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
 #endif
 constexpr int kBigRows = 64, kBigCols = 64, kBigK = MOPOE_BIGK, kBigLd = kBigK + 4;
 constexpr int kBigTpr = kBigK / 4;           // staging threads per row (a float4 each)
-constexpr int kBigRpp = 256 / kBigTpr;       // rows per staging pass
-constexpr int kBigPasses = kBigRows / kBigRpp;
-constexpr int kLinBigRows = 2048;  // batches from here on use it
+constexpr int kLinBigRows = 2048;  // batches from here on use the 64-row tiles
 
-__global__ __launch_bounds__(256) void k_linear_big(const LinArgs a_by_value) {
+// ROWS = 64: four waves, a 16 x 64 strip each.  (Measured and dropped: ROWS = 32 for batches of
+// ~1,000 rows -- twice the workgroups, but a workgroup's chain of fourteen load - park - barrier
+// rounds takes 20 us whatever its size: 1,024 rows 20.4 us against 16.0 with the 16-row tiles.)
+template <int ROWS>
+__global__ __launch_bounds__(ROWS * 4) void k_linear_big(const LinArgs a_by_value) {
     (void)a_by_value;  // read in place (see k_latent)
     const LinArgs& a = *(const LinArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    __shared__ __attribute__((aligned(16))) float As[2][kBigRows * kBigLd];
+    constexpr int T = ROWS * 4;                  // threads: a wave per 16-row strip
+    constexpr int RPP = T / kBigTpr;             // rows per staging pass
+    constexpr int PA = ROWS / RPP, PB = kBigCols / RPP;   // passes over the x rows / the W rows
+    static_assert(PA >= 1 && PB >= 1 && ROWS % RPP == 0 && kBigCols % RPP == 0, "staging split");
+    __shared__ __attribute__((aligned(16))) float As[2][ROWS * kBigLd];
     __shared__ __attribute__((aligned(16))) float Bs[2][kBigCols * kBigLd];
-    __shared__ int rowsel[kBigRows];
+    __shared__ int rowsel[ROWS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, q = lane >> 4;
@@ -497,10 +503,10 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a_by_value) {
         step_begin(a.counters, a.num_mods, a.publish ? &a.adam : nullptr);
     }
     const LinGroup& g = a.g[blockIdx.z];
-    const int j0 = blockIdx.x * kBigCols, n0 = blockIdx.y * kBigRows;
+    const int j0 = blockIdx.x * kBigCols, n0 = blockIdx.y * ROWS;
     if (j0 >= g.ncols) return;
     const int K = g.K;
-    if (tid < kBigRows) {
+    if (tid < ROWS) {
         const int gn = min(n0 + tid, N - 1);
         rowsel[tid] = g.rows ? g.rows[gn] : gn;
     }
@@ -508,35 +514,42 @@ __global__ __launch_bounds__(256) void k_linear_big(const LinArgs a_by_value) {
     const rsrc_t xr = make_rsrc(g.X, (size_t)g.xrows * g.ldx * sizeof(float));
     const rsrc_t wr = make_rsrc(g.W, (size_t)g.ncols * K * sizeof(float));
     const bool vec = K % 4 == 0;
-    // staging: thread -> 4 float4 of the x chunk and 4 of the W chunk (rows r0 + 16 i)
+    // staging: thread -> PA float4 of the x chunk and PB of the W chunk (rows r0 + RPP i)
     const int r0 = tid / kBigTpr, k4 = (tid % kBigTpr) * 4;
-    f32x4 xa[kBigPasses], wb[kBigPasses];
+    f32x4 xa[PA], wb[PB];
     auto fetch = [&](int kc) __attribute__((always_inline)) {
+        const int k = kc + k4;
 #pragma unroll
-        for (int i = 0; i < kBigPasses; ++i) {
-            const int r = r0 + kBigRpp * i, k = kc + k4;
+        for (int i = 0; i < PA; ++i) {
+            const int r = r0 + RPP * i;
             const uint32_t xo = (uint32_t)(rowsel[r] * g.ldx + k) * 4u;
-            const uint32_t wo = (uint32_t)((j0 + r) * K + k) * 4u;   // row >= ncols: out of range
             const bool rv = n0 + r < N;
             if (vec) {
                 xa[i] = ldg4(xr, guard(xo, rv & (k < K)));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xa[i][e] = ldg(xr, guard(xo + 4u * e, rv & (k + e < K)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int r = r0 + RPP * i;
+            const uint32_t wo = (uint32_t)((j0 + r) * K + k) * 4u;   // row >= ncols: out of range
+            if (vec) {
                 wb[i] = ldg4(wr, guard(wo, k < K));
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    xa[i][e] = ldg(xr, guard(xo + 4u * e, rv & (k + e < K)));
-                    wb[i][e] = ldg(wr, guard(wo + 4u * e, k + e < K));
-                }
+                for (int e = 0; e < 4; ++e) wb[i][e] = ldg(wr, guard(wo + 4u * e, k + e < K));
             }
         }
     };
     auto park = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < kBigPasses; ++i) {
-            const int r = r0 + kBigRpp * i;
-            *reinterpret_cast<f32x4*>(&As[buf][r * kBigLd + k4]) = xa[i];
-            *reinterpret_cast<f32x4*>(&Bs[buf][r * kBigLd + k4]) = wb[i];
-        }
+        for (int i = 0; i < PA; ++i)
+            *reinterpret_cast<f32x4*>(&As[buf][(r0 + RPP * i) * kBigLd + k4]) = xa[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            *reinterpret_cast<f32x4*>(&Bs[buf][(r0 + RPP * i) * kBigLd + k4]) = wb[i];
     };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[4] = {zero4, zero4, zero4, zero4};
@@ -2109,8 +2122,7 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s, 
     const size_t lds = ((size_t)kRows * (kp + 4) + kLinRedFloats) * sizeof(float);
     if (la.n >= g_knobs.lin_big_rows) {
         ProfScope ps(MOPOE_KERNEL_LINEAR, s);
-        hipLaunchKernelGGL(k_linear_big,
-                           dim3(cdiv(max_cols, kBigCols), cdiv(la.n, kBigRows), la.ngroups),
+        hipLaunchKernelGGL(k_linear_big<64>, dim3(cdiv(max_cols, kBigCols), cdiv(la.n, 64), la.ngroups),
                            dim3(256), 0, s, la);
         return check_launch("k_linear_big");
     }

@@ -45,7 +45,8 @@ def run(method, n, env):
 
 
 for rnd in range(2):
-    for method, n in (("poe", 1024), ("joint_elbo", 768), ("joint_elbo", 1024)):
+    for method, n in (("poe", 512), ("poe", 1024), ("joint_elbo", 384), ("joint_elbo", 512), ("joint_elbo", 640),
+                      ("joint_elbo", 768), ("joint_elbo", 1024)):
         run(method, n, {"MOPOE_QUAD_MAX_N": "256"})     # sixteen-row groups, producers in the launch
-        run(method, n, {"MOPOE_QUAD_MAX_N": "1024"})    # four-row groups, the encoder layer a launch of its own
-        run(method, n, {"MOPOE_QUAD_MAX_N": "1024", "MOPOE_LIN_BIG_ROWS": "512"})   # ... in 64 x 64 tiles
+        run(method, n, {"MOPOE_QUAD_MAX_N": "1024"})    # four-row groups (the encoder layer a launch of its own
+                                                        # where the producers do not fit beside them)
