@@ -33,11 +33,14 @@ TOPOLOGIES = [
 def main():
     device = torch.device("cuda")
     steps, warmup = 400, 100
-    for key in ("C1", "C5"):
+    only = os.environ.get("TOPOLOGY_ONLY")      # (profiling: one topology, by its label)
+    for key in os.environ.get("TOPOLOGY_CONFIGS", "C1,C5").split(","):
         c = bench.CONFIGS[key]
         print(c["label"])
         base = None
         for label, topo in TOPOLOGIES:
+            if only and label != only:
+                continue
             kw = dict(topo)
             method = kw.pop("method", c["method"])
             spec = mm.ModelSpec(c["names"], c["dims"], c["style"], class_dim=bench.LATENT,
