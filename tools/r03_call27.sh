@@ -19,4 +19,4 @@ t0 = int(rows[a]["Start_Timestamp"])
 for r in rows[a:b]:
     print("%8.1f us  +%6.1f  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Kernel_Name"][:80]))
 PY
-python tools/daa_bench.py 2>&1 | grep -v amdgpu.ids | tail -8
+
