@@ -334,8 +334,12 @@ class ResidentCohort:
         mods = self.dataset.modalities
         nb, M = len(out_subset), len(mods)
         lens = np.diff(out_begin)
-        has = np.array([[m in sub for m in mods] for sub in self.dataset.modality_subsets],
-                       dtype=np.uint8)
+        cache = self.__dict__.setdefault("_sched_cache", {})
+        if cache.get("subsets") is not self.dataset.modality_subsets:   # (per cohort, not per epoch)
+            cache["subsets"] = self.dataset.modality_subsets
+            cache["has"] = np.ascontiguousarray(
+                [[m in sub for m in mods] for sub in self.dataset.modality_subsets], dtype=np.uint8)
+        has = cache["has"]
         per_batch = has[out_subset].astype(bool) if nb else np.zeros((0, M), bool)
         indices = None
         if self.dataset.indices is not None:
@@ -360,6 +364,24 @@ class ResidentCohort:
                     starts={m: v.tolist() for m, v in starts.items()})
 
     @staticmethod
+    def _global_mt():
+        """(key, pos) of numpy's global legacy generator IN PLACE -- a view of the 624 state
+        words and the position word behind them (numpy's mt19937_state: `uint32_t key[624];
+        int pos;`) -- or None where that generator is not the MT19937 the legacy API promises.
+        np.random.get_state() + set_state() copy and validate the state: 115 us per epoch,
+        a quarter of a 14-step epoch; a look and a write in place are 4 us."""
+        import ctypes as C
+        try:
+            bg = np.random.mtrand._rand._bit_generator
+            if type(bg).__name__ != "MT19937":
+                return None
+            addr = bg.ctypes.state_address
+            key = np.ctypeslib.as_array((C.c_uint32 * 624).from_address(addr))
+            return key, C.c_int32.from_address(addr + 624 * 4)
+        except (AttributeError, TypeError, ValueError):
+            return None
+
+    @staticmethod
     def _same_state(a, b):
         return a[0] == b[0] and a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and \
             np.array_equal(a[1], b[1])
@@ -378,21 +400,34 @@ class ResidentCohort:
         global stream always reads as if the reference's sampler had drawn at this moment."""
         if world > 1:
             return self._epoch_schedule_ranks(batch_size, world, rank)
-        now = np.random.get_state()
         host = None
+        live = self._global_mt()     # (the generator's words in place; None: through get / set_state)
+        now = np.random.get_state() if live is None else None
         pre, self._prefetch = getattr(self, "_prefetch", None), None
         if pre is not None:
             try:
                 ahead = pre["future"].result()
             except Exception:      # (the same error surfaces from the foreground draw below)
                 ahead = None
-            if ahead is not None and pre["batch_size"] == batch_size and \
-                    self._same_state(pre["state"], now):
-                host = ahead
+            if ahead is not None and pre["batch_size"] == batch_size:
+                if live is not None:
+                    # the stream is where the prefetch started from iff key and position are
+                    # (the cached-gaussian words of the legacy state do not enter the draws)
+                    same = live[1].value == pre["state"][2] and np.array_equal(live[0], pre["state"][1])
+                else:
+                    same = self._same_state(pre["state"], now)
+                if same:
+                    host = ahead
         turn = self.__dict__.get("_turn", 0)
         if host is None:
+            if now is None:
+                now = np.random.get_state()
             host = self._host_schedule(now, batch_size, self._staging(turn % 2))
-        np.random.set_state(host["after"])
+        if live is not None:        # the stream moves on by exactly the sampler's draws
+            live[0][:] = host["after"][1]
+            live[1].value = host["after"][2]
+        else:
+            np.random.set_state(host["after"])
         if getattr(self, "_pool", None) is None:
             from concurrent.futures import ThreadPoolExecutor
             self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mopoe-sampler")
