@@ -2743,7 +2743,13 @@ int mopoe_ldz(const mopoe_model* mdl, int mod) { return ldz_glb(*mdl, mod); }
 
 int mopoe_partials_stride(const mopoe_model* mdl) { return partials_stride(*mdl); }
 int64_t mopoe_wgrad_scratch_floats(const mopoe_model* mdl, const mopoe_step* st) {
-    if (!mdl || !st || st->n < 1 || !wgrad_big_step(*st)) return 0;
+    if (!mdl || !st || st->n < 1) return 0;
+    if (!st->backward) {   // mopoe_forward: sixteen pre-summed slabs, from 64 row groups on
+        LatentLds L;
+        step_layout(*mdl, *st, L);
+        return cdiv(st->n, L.rows) >= 4 * kFoldSlices ? (int64_t)kFoldSlices * partials_stride(*mdl) : 0;
+    }
+    if (!wgrad_big_step(*st)) return 0;
     KArgs ka;
     memset(&ka, 0, sizeof(ka));
     ka.mdl = *mdl;
@@ -2777,6 +2783,16 @@ int mopoe_forward(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buff
     if (int rc = launch_forward_part(ka, nullptr, s)) return rc;
     {
         ProfScope ps(MOPOE_KERNEL_FINALIZE, s);
+        // thousands of row groups (folded DAA inference): their slabs are summed in sixteen
+        // slices by a launch of many blocks first -- the one finalising block walked 3,125
+        // slabs in 27 us at 50,000 rows -- when the caller gave the scratch for it
+        const int groups = cdiv(ka.st.n, ka.lds.rows);
+        if (buf->wgrad_scratch && groups >= 4 * kFoldSlices) {
+            hipLaunchKernelGGL(k_partials_fold, dim3(cdiv(kStatStride, 256), kFoldSlices), dim3(256), 0, s,
+                               (const float*)buf->partials, buf->wgrad_scratch, groups, ka.lds.part_stride);
+            ka.buf.partials = buf->wgrad_scratch;
+            ka.lds.fold_tiles = kFoldSlices;
+        }
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, ka);
     }
     return check_launch("k_finalize");

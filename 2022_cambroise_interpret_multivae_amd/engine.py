@@ -479,6 +479,11 @@ class MoPoEEngine:
         keep = self._bind_noise(plan, step, eps)
         self._calls += 1
         step.seed = (self.seed + 0x9E3779B97F4A7C15 * self._calls) & (2 ** 64 - 1)
+        if ws.wgrad_scratch is None and not self.spec.general:
+            # thousands of row groups: scratch for their pre-summed slabs (k_partials_fold)
+            need = L.lib.mopoe_wgrad_scratch_floats(self.spec.c_model, step)
+            ws.wgrad_scratch = torch.empty(need, **ws._f) if need else False
+            ws._cbuf = None
         buf = self._buffers(ws, x, row_index, plan=plan)
         if self.spec.general:       # (evaluation: the Dropout modules are the identity)
             self._bind_masks(plan, ws, None, False)
