@@ -13,7 +13,7 @@ MAX_SUBSETS = 31
 MAX_JOBS = 10
 HIDDEN = 256
 ROWS = 16
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_RANKS = 8
 IPC_HANDLE_BYTES = 64
 RCCL_ID_BYTES = 128
@@ -94,6 +94,8 @@ class Step(C.Structure):
         ("job_eps_content", _ptr * MAX_JOBS),
         ("job_eps_style", _ptr * MAX_JOBS),
         ("seed", C.c_uint64),
+        ("gemm_operands", _i32),
+        ("pad_", _i32),
     ]
 
 

@@ -141,6 +141,7 @@ struct LinArgs {
     int32_t num_mods;      // modalities of the model (the Adam records of step_begin)
     int32_t spins;         // fused launch: polls of a row group before it gives up
     int32_t knock;         // (diagnostic build -DMOPOE_KNOCK: phases to leave out)
+    int32_t bf16;          // mopoe_step.gemm_operands == MOPOE_OPERANDS_BF16 (k_linear_big only)
     int32_t sig_n, sig_stride, sig_groups;   // fused launch: row groups per 16-row tile, words
                                              // between their flags, row groups in all
     mopoe_adam adam;
@@ -474,26 +475,43 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
 // MFMAs), and each of its four waves accumulates a 16 x 64 strip -> 16 flop per byte.
 // grid = (column groups of 64, row tiles of 64, groups), block = 256.
 // ---------------------------------------------------------------------------
+#ifndef MOPOE_BIGK_BF16
+#define MOPOE_BIGK_BF16 64
+#endif
 #ifndef MOPOE_BIGK
 #define MOPOE_BIGK 32
 #endif
 constexpr int kBigRows = 64, kBigCols = 64, kBigK = MOPOE_BIGK, kBigLd = kBigK + 4;
-constexpr int kBigTpr = kBigK / 4;           // staging threads per row (a float4 each)
 constexpr int kLinBigRows = 2048;  // batches from here on use the 64-row tiles
 
 // ROWS = 64: four waves, a 16 x 64 strip each.  (Measured and dropped: ROWS = 32 for batches of
 // ~1,000 rows -- twice the workgroups, but a workgroup's chain of fourteen load - park - barrier
 // rounds takes 20 us whatever its size: 1,024 rows 20.4 us against 16.0 with the 16-row tiles.)
-template <int ROWS>
+// BF16 (mopoe_step.gemm_operands, opt-in): x and W are rounded to bfloat16 (nearest even) as
+// they are parked -- two k per LDS word, K chunks twice as deep in the same bytes -- and
+// multiplied by v_mfma_f32_16x16x16_bf16 with float32 accumulation: one instruction for the
+// four exact-f32 ones of a 16-deep K block (lane (c, q) supplies k = kb + 4 q .. + 3 of row /
+// column c for both operands: tools/mfma_bf16_probe.hip).
+DEV uint32_t bf16_pair(float lo, float hi) {   // two roundings to nearest even, packed (finite inputs)
+    uint32_t a = __builtin_bit_cast(uint32_t, lo), b = __builtin_bit_cast(uint32_t, hi);
+    a += 0x7FFFu + ((a >> 16) & 1u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xFFFF0000u);
+}
+
+template <int ROWS, bool BF16>
 __global__ __launch_bounds__(ROWS * 4) void k_linear_big(const LinArgs a_by_value) {
     (void)a_by_value;  // read in place (see k_latent)
     const LinArgs& a = *(const LinArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int T = ROWS * 4;                  // threads: a wave per 16-row strip
-    constexpr int RPP = T / kBigTpr;             // rows per staging pass
+    constexpr int KC = BF16 ? MOPOE_BIGK_BF16 : kBigK; // k per staged chunk
+    constexpr int TPR = KC / 4;                  // staging threads per row (a float4 each)
+    constexpr int RPP = T / TPR;                 // rows per staging pass
     constexpr int PA = ROWS / RPP, PB = kBigCols / RPP;   // passes over the x rows / the W rows
     static_assert(PA >= 1 && PB >= 1 && ROWS % RPP == 0 && kBigCols % RPP == 0, "staging split");
-    __shared__ __attribute__((aligned(16))) float As[2][ROWS * kBigLd];
-    __shared__ __attribute__((aligned(16))) float Bs[2][kBigCols * kBigLd];
+    constexpr int LD = BF16 ? KC / 2 + 2 : KC + 4;        // LDS words per row (bf16: two k per word)
+    __shared__ __attribute__((aligned(16))) float As[2][ROWS * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kBigCols * LD];
     __shared__ int rowsel[ROWS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -515,7 +533,7 @@ __global__ __launch_bounds__(ROWS * 4) void k_linear_big(const LinArgs a_by_valu
     const rsrc_t wr = make_rsrc(g.W, (size_t)g.ncols * K * sizeof(float));
     const bool vec = K % 4 == 0;
     // staging: thread -> PA float4 of the x chunk and PB of the W chunk (rows r0 + RPP i)
-    const int r0 = tid / kBigTpr, k4 = (tid % kBigTpr) * 4;
+    const int r0 = tid / TPR, k4 = (tid % TPR) * 4;
     f32x4 xa[PA], wb[PB];
     auto fetch = [&](int kc) __attribute__((always_inline)) {
         const int k = kc + k4;
@@ -544,33 +562,62 @@ __global__ __launch_bounds__(ROWS * 4) void k_linear_big(const LinArgs a_by_valu
         }
     };
     auto park = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (BF16) {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int i = 0; i < PA; ++i)
-            *reinterpret_cast<f32x4*>(&As[buf][(r0 + RPP * i) * kBigLd + k4]) = xa[i];
+            for (int i = 0; i < PA; ++i) {
+                const u32x2 v = {bf16_pair(xa[i][0], xa[i][1]), bf16_pair(xa[i][2], xa[i][3])};
+                *reinterpret_cast<u32x2*>(&As[buf][(r0 + RPP * i) * LD + k4 / 2]) = v;
+            }
 #pragma unroll
-        for (int i = 0; i < PB; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[buf][(r0 + RPP * i) * kBigLd + k4]) = wb[i];
+            for (int i = 0; i < PB; ++i) {
+                const u32x2 v = {bf16_pair(wb[i][0], wb[i][1]), bf16_pair(wb[i][2], wb[i][3])};
+                *reinterpret_cast<u32x2*>(&Bs[buf][(r0 + RPP * i) * LD + k4 / 2]) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PA; ++i)
+                *reinterpret_cast<f32x4*>(&As[buf][(r0 + RPP * i) * LD + k4]) = xa[i];
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                *reinterpret_cast<f32x4*>(&Bs[buf][(r0 + RPP * i) * LD + k4]) = wb[i];
+        }
     };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[4] = {zero4, zero4, zero4, zero4};
     fetch(0);
     park(0);
     __syncthreads();
-    const int nchunks = cdiv(K, kBigK);
+    const int nchunks = cdiv(K, KC);
     for (int c = 0; c < nchunks; ++c) {
         const int cur = c & 1;
-        if (c + 1 < nchunks) fetch((c + 1) * kBigK);   // in flight under the MFMAs
-        const float* Aw = &As[cur][(wave * 16) * kBigLd];
+        if (c + 1 < nchunks) fetch((c + 1) * KC);   // in flight under the MFMAs
+        const float* Aw = &As[cur][(wave * 16) * LD];
+        if constexpr (BF16) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int kb = 0; kb < kBigK; kb += 16) {
-            const f32x4 av = lds_a4(Aw, kBigLd, kb, lane);
-            f32x4 bv[4];
+            for (int kb = 0; kb < KC; kb += 16) {
+                const int o = c16 * LD + kb / 2 + 2 * q;   // (four consecutive k: two words)
+                const s16x4 av = *reinterpret_cast<const s16x4*>(Aw + o);
+                s16x4 bv[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bv[t] = lds_a4(&Bs[cur][(16 * t) * kBigLd], kBigLd, kb, lane);
+                for (int t = 0; t < 4; ++t) bv[t] = *reinterpret_cast<const s16x4*>(&Bs[cur][(16 * t) * LD + o]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int t = 0; t < 4; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv[t], acc[t], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = mfma_16x16x4(av[i], bv[t][i], acc[t]);
+            for (int kb = 0; kb < KC; kb += 16) {
+                const f32x4 av = lds_a4(Aw, LD, kb, lane);
+                f32x4 bv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bv[t] = lds_a4(&Bs[cur][(16 * t) * LD], LD, kb, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = mfma_16x16x4(av[i], bv[t][i], acc[t]);
+            }
         }
         if (c + 1 < nchunks) {
             park(cur ^ 1);   // the other buffer was last read before the previous barrier
@@ -1805,6 +1852,8 @@ int check_launch(const char* what) {
 int validate(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* buf,
              bool train) {
     if (!mdl || !st || !buf) return fail(MOPOE_ERR_ARG, "null descriptor%s");
+    if (st && (st->gemm_operands != MOPOE_OPERANDS_F32 && st->gemm_operands != MOPOE_OPERANDS_BF16))
+        return fail(MOPOE_ERR_ARG, "mopoe_step.gemm_operands: MOPOE_OPERANDS_F32 or MOPOE_OPERANDS_BF16%s");
     if (mdl->num_mods < 1 || mdl->num_mods > MOPOE_MAX_MODS)
         return fail(MOPOE_ERR_ARG, "num_mods out of range%s");
     if (mdl->class_dim < 1 || mdl->class_dim > 256)
@@ -2122,8 +2171,12 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s, 
     const size_t lds = ((size_t)kRows * (kp + 4) + kLinRedFloats) * sizeof(float);
     if (la.n >= g_knobs.lin_big_rows) {
         ProfScope ps(MOPOE_KERNEL_LINEAR, s);
-        hipLaunchKernelGGL(k_linear_big<64>, dim3(cdiv(max_cols, kBigCols), cdiv(la.n, 64), la.ngroups),
-                           dim3(256), 0, s, la);
+        if (la.bf16)
+            hipLaunchKernelGGL((k_linear_big<64, true>), dim3(cdiv(max_cols, kBigCols), cdiv(la.n, 64), la.ngroups),
+                               dim3(256), 0, s, la);
+        else
+            hipLaunchKernelGGL((k_linear_big<64, false>), dim3(cdiv(max_cols, kBigCols), cdiv(la.n, 64), la.ngroups),
+                               dim3(256), 0, s, la);
         return check_launch("k_linear_big");
     }
     // K parts per column tile: as many as it takes to put ~2 workgroups on every CU
@@ -2179,6 +2232,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     la.publish = adam != nullptr;
     la.num_mods = mdl.num_mods;
     la.spins = handoff_spins();
+    la.bf16 = ka.st.gemm_operands == MOPOE_OPERANDS_BF16;
 #ifdef MOPOE_KNOCK
     la.knock = g_knobs.knock;
 #endif

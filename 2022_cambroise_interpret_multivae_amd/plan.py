@@ -32,7 +32,7 @@ class ModelSpec:
                  learn_output_scale=True, lr=0.002, betas=(0.9, 0.999),
                  adam_eps=1e-8, rec_weights=None, poe_unimodal_elbos=True,
                  likelihood="normal", enc_layers=1, dec_layers=0, dropout=0.0,
-                 sample_scale=False):
+                 sample_scale=False, gemm_operands=None):
         if method not in METHODS:
             raise NotImplementedError(
                 "method %r: only joint_elbo / poe / moe are on the MI355X hot "
@@ -70,6 +70,15 @@ class ModelSpec:
                 "likelihood %r: the decoder's (loc, scale) output feeds Normal or Laplace"
                 % (likelihood,))
         self.likelihood = likelihood
+        # what the encoder layer's GEMM of a LARGE batch multiplies (mopoe_step.gemm_operands):
+        # "f32" -- the reference's arithmetic, the default -- or "bf16" (opt-in, BASELINE
+        # configs[1]'s "bf16 compute / fp32 accumulate": operands rounded to bfloat16, float32
+        # accumulation; tests/test_oracle_precision.py measures what it costs)
+        if gemm_operands is None:
+            gemm_operands = os.environ.get("MOPOE_GEMM_OPERANDS", "f32")
+        if gemm_operands not in ("f32", "bf16"):
+            raise ValueError("gemm_operands: 'f32' or 'bf16'")
+        self.gemm_operands = gemm_operands
         self.rec_weights = dict(rec_weights) if rec_weights else \
             {n: 1.0 for n in self.names}
 
@@ -264,6 +273,7 @@ class StepPlan:
         st.group_rows = int(group_rows)
         st.num_subsets = len(spec.subset_keys)
         st.likelihood = L.LIKELIHOODS[spec.likelihood]
+        st.gemm_operands = 1 if spec.gemm_operands == "bf16" else 0
 
         # subsets (BaseMMVae.inference :190-216)
         self.avail_keys = []

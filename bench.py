@@ -254,11 +254,15 @@ def other_config(key, device, steps=1000, warmup=300):
             "roofline": roofline_of(spec, c["batch"], prof, dt / steps, True, 1, traffic=key)}
 
 
-def regime_point(device, n=65536):
+def regime_point(device, n=65536, operands="f32"):
     """The kernels of configs[1]'s model at 65,536 rows (the
-    bandwidth / MFMA regime, where the batch term dominates the per-step terms)."""
+    bandwidth / MFMA regime, where the batch term dominates the per-step terms).
+    operands="bf16": the opt-in that BASELINE configs[1] names (the encoder layer's GEMM
+    on bfloat16 roundings, float32 sums) -- reported NEXT to the float32 figures, never
+    instead of them."""
     c = dict(CONFIGS["C1"], batch=n)
-    spec = make_spec(c)
+    spec = mm.ModelSpec(c["names"], c["dims"], c["style"], class_dim=LATENT, method=c["method"],
+                        gemm_operands=operands)
     eng = mm.MoPoEEngine(spec, device, seed=1)
     eng.reset_parameters(torch.Generator().manual_seed(0))
     pool = make_pool(c, device, count=2)
@@ -278,8 +282,8 @@ def regime_point(device, n=65536):
     prof = mm._lib.profile_read()
     mm._lib.profile_enable(False)
     models = kernel_models(spec, n, True)
-    out = {"rows": n, "ms_per_step": round(1e3 * dt, 4), "samples_per_s": round(n / dt, 1),
-           "kernels": {}}
+    out = {"rows": n, "encoder_layer_operands": operands, "ms_per_step": round(1e3 * dt, 4),
+           "samples_per_s": round(n / dt, 1), "kernels": {}}
     for k, (cnt, ms) in prof.items():
         if not cnt:
             continue
@@ -780,6 +784,7 @@ def main():
         for c_ in out["loop"]["cohorts"]:
             c_["ratio_to_bare_engine_loop"] = round(c_["us_per_step"] / (1e3 * out["ms_per_step"]), 3)
         out["regime_n65536"] = regime_point(device)
+        out["regime_n65536_bf16_operands"] = regime_point(device, operands="bf16")
         out["eager_rocm_baseline"] = eager_rocm_baseline(device)
     if single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 9
+#define MOPOE_ABI_VERSION 10
 #define MOPOE_MAX_MODS 5      /* modalities                                   */
 #define MOPOE_MAX_SUBSETS 31  /* 2^MAX_MODS - 1 non-empty subsets             */
 #define MOPOE_MAX_JOBS 10     /* decoder passes: 1 joint + 1 unimodal per mod */
@@ -49,6 +49,8 @@ extern "C" {
 #define MOPOE_SUB_SLICES 2     /* moe_fusion: contiguous row slices of members */
 
 /* joint_mode: BaseMMVae.inference (utils/BaseMMVae.py:226-231) */
+#define MOPOE_OPERANDS_F32 0
+#define MOPOE_OPERANDS_BF16 1
 #define MOPOE_LIK_NORMAL 0     /* torch.distributions.Normal(loc, scale)       */
 #define MOPOE_LIK_LAPLACE 1    /* torch.distributions.Laplace(loc, scale)      */
 #define MOPOE_JOINT_MIXTURE 0  /* sample=True: mixture_component_selection     */
@@ -200,6 +202,13 @@ typedef struct mopoe_step {
     const float* job_eps_content[MOPOE_MAX_JOBS]; /* (n, class_dim)            */
     const float* job_eps_style[MOPOE_MAX_JOBS];   /* (n, style_dim[m])         */
     uint64_t seed;
+    int32_t gemm_operands;  /* MOPOE_OPERANDS_*: what the encoder layer's GEMM of a LARGE batch
+                               (from 2,048 rows: k_linear_big) multiplies -- the float32 values
+                               (0, default: the reference's arithmetic, exact-f32 MFMA) or their
+                               bfloat16 roundings with float32 accumulation (1, opt-in: BASELINE
+                               configs[1] names "bf16 compute / fp32 accumulate"; what it costs in
+                               accuracy is measured in tests/test_oracle_precision.py).  ABI 10  */
+    int32_t pad_;
 } mopoe_step;
 
 /* ---------------------------------------------------------------------------

@@ -38,7 +38,8 @@ class Config:
                  beta_style=1.0, beta_content=1.0, initial_out_logvar=-3.0,
                  learn_output_scale=True, lr=0.002, betas=(0.9, 0.999),
                  adam_eps=1e-8, poe_unimodal_elbos=True, likelihood="normal",
-                 enc_layers=1, dec_layers=0, dropout=0.0, sample_scale=False):
+                 enc_layers=1, dec_layers=0, dropout=0.0, sample_scale=False,
+                 gemm_operands="f32"):
         assert method in ("joint_elbo", "poe", "moe")
         # experiments/workflow.py:41-49: num_hidden_layer_encoder / _decoder, dropout_rate,
         # out_scale_per_subject (-> flags.learn_output_sample_scale, workflow.py:112)
@@ -46,6 +47,11 @@ class Config:
         self.dec_layers = int(dec_layers)
         self.dropout = float(dropout)
         self.sample_scale = bool(sample_scale)
+        # NOT a reference switch: the opt-in of the HIP path (mopoe_step.gemm_operands) whose
+        # definition this restates so that it can be checked and its cost measured -- the
+        # first encoder layer multiplies the bfloat16 roundings of x and W (float32 sums)
+        assert gemm_operands in ("f32", "bf16")
+        self.gemm_operands = gemm_operands
         # experiments/modalities/modality.py:18-30: the decoder's (loc, scale) pair feeds
         # torch.distributions.Normal or Laplace (Bernoulli / OneHotCategorical take other
         # arguments than the pair this decoder returns)
@@ -258,15 +264,32 @@ def calc_group_divergence_moe(mus, logvars, weights, normalization):
 # --------------------------------------------------------------------------
 # L1 model (networks.py, BaseMMVae.py)
 # --------------------------------------------------------------------------
-def _hidden_stack(params, prefix, layers, h, cfg, noise, train):
+class _Bf16Linear(torch.autograd.Function):
+    """y = round_bf16(x) round_bf16(W)^T + b with float32 accumulation; the backward is the
+    float32 layer's (dW = g^T x with the UNROUNDED x, db = sum g): rounding is looked
+    through, as the HIP path's weight-gradient kernel does (it never sees the roundings)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.linear(x.bfloat16().float(), w.bfloat16().float(), b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        return g @ w, g.t() @ x, g.sum(0)
+
+
+def _hidden_stack(params, prefix, layers, h, cfg, noise, train, first_bf16=False):
     """nn.Sequential of `layers` x (Linear, ReLU, Dropout(cfg.dropout))
     (networks.py:16-20,51-55).  Dropout in training mode is ATen's
     x * (bernoulli(1 - p) / (1 - p)); the keep masks come off the noise object's
     mask tape in call order (the reference draws them from torch's global RNG)."""
     lin = torch.nn.functional.linear
     for l in range(layers):
-        h = torch.relu(lin(h, params[prefix + "%d.weight" % (3 * l)],
-                           params[prefix + "%d.bias" % (3 * l)]))
+        op = _Bf16Linear.apply if (first_bf16 and l == 0) else lin
+        h = torch.relu(op(h, params[prefix + "%d.weight" % (3 * l)],
+                          params[prefix + "%d.bias" % (3 * l)]))
         if train and cfg.dropout > 0.0:
             keep = noise.keep_mask(h.shape, cfg.dropout)
             h = h * (keep / (1.0 - cfg.dropout))
@@ -279,7 +302,8 @@ def encoder_forward(params, cfg, m, x, noise=None, train=False):
     when not factorized / style_dim 0; h = what the heads read."""
     e = "encoders.%s." % cfg.names[m]
     lin = torch.nn.functional.linear
-    h = _hidden_stack(params, e + "shared_encoder.", cfg.enc_layers, x, cfg, noise, train)
+    h = _hidden_stack(params, e + "shared_encoder.", cfg.enc_layers, x, cfg, noise, train,
+                      first_bf16=getattr(cfg, "gemm_operands", "f32") == "bf16")
     c_mu = lin(h, params[e + "class_mu.weight"], params[e + "class_mu.bias"])
     c_lv = lin(h, params[e + "class_logvar.weight"],
                params[e + "class_logvar.bias"])

@@ -67,7 +67,8 @@ def make_engine(cfg, device="cuda"):
                         poe_unimodal_elbos=cfg.poe_unimodal_elbos,
                         likelihood=cfg.likelihood, enc_layers=cfg.enc_layers,
                         dec_layers=cfg.dec_layers, dropout=cfg.dropout,
-                        sample_scale=cfg.sample_scale)
+                        sample_scale=cfg.sample_scale,
+                        gemm_operands=getattr(cfg, "gemm_operands", "f32"))
     eng = mm.MoPoEEngine(spec, device)
     eng.load_params(mo.init_params(cfg, 0))
     return spec, eng

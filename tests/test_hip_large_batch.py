@@ -19,8 +19,12 @@ C5 = dict(names=["clinical", "rois", "snps", "tracts"], input_dim=[7, 444, 128, 
 
 @pytest.mark.parametrize("base,method,n,extra", [
     (C1, "joint_elbo", 4096 + 37, {}), (C1, "poe", 4100, {}), (C5, "joint_elbo", 4096, {}),
-    (C1, "moe", 5000, dict(learn_output_scale=False, factorized=False))],
-    ids=["c1_ragged", "c1_poe", "c5", "c1_moe_frozen_scale"])
+    (C1, "moe", 5000, dict(learn_output_scale=False, factorized=False)),
+    # the opt-in bfloat16 operands of the encoder layer (mopoe_step.gemm_operands) against
+    # their definition (oracle: roundings of x and W, float32 sums, float32 backward) -- the
+    # products of bfloat16 values are exact in float32, so the tolerances stay what they are
+    (C1, "joint_elbo", 4096 + 37, dict(gemm_operands="bf16"))],
+    ids=["c1_ragged", "c1_poe", "c5", "c1_moe_frozen_scale", "c1_bf16_operands"])
 @pytest.mark.parametrize("form", ["split", "one_launch"])
 def test_large_batch_step_matches_oracle(base, method, n, extra, form):
     cfg = mo.Config(method=method, **base, **extra)
@@ -52,7 +56,10 @@ def test_large_batch_step_matches_oracle(base, method, n, extra, form):
     near_kink = {}
     for name in x:
         e = "encoders.%s.shared_encoder.0." % name
-        pre = x[name].double() @ init[e + "weight"].double().t() + init[e + "bias"].double()
+        xs, ws_ = x[name], init[e + "weight"]
+        if cfg.gemm_operands == "bf16":
+            xs, ws_ = xs.bfloat16(), ws_.bfloat16()
+        pre = xs.double() @ ws_.double().t() + init[e + "bias"].double()
         near_kink[name] = (pre.abs() < 3e-6).any(0)
     skipped = sum(int(v.sum()) for v in near_kink.values())
     assert skipped <= 32, skipped

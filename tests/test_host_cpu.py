@@ -212,5 +212,5 @@ def test_hot_kernels_keep_their_registers_and_scratch():
         assert pick(frag)["vgpr"] <= 128 and pick(frag)["scratch"] <= 64, (frag, pick(frag))
     assert linear["scratch"] == 0, linear
     for frag in ("k_wgradILi4ELb0", "k_wgradILi8ELb0", "k_wgradILi4ELb1", "k_wgradILi8ELb1",
-                 "k_adamE", "k_xgmiE", "k_linear_bigILi64EE"):
+                 "k_adamE", "k_xgmiE", "k_linear_bigILi64ELb0EE", "k_linear_bigILi64ELb1EE"):
         assert pick(frag)["scratch"] == 0, (frag, pick(frag))
