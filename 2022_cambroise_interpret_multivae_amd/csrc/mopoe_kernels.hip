@@ -2576,7 +2576,7 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
         // walking all of them (65,536 rows: 47 -> ~10 us)
         KArgs kt = ka;
         const int groups = cdiv(ka.st.n, ka.lds.rows);
-        const bool fold = groups >= 4 * kFoldSlices;
+        const bool fold = groups >= 8 * kFoldSlices;
         if (fold) {
             kt.buf.partials = buf->wgrad_scratch + wb_floats;
             kt.lds.fold_tiles = kFoldSlices;
@@ -2798,10 +2798,10 @@ int mopoe_ldz(const mopoe_model* mdl, int mod) { return ldz_glb(*mdl, mod); }
 int mopoe_partials_stride(const mopoe_model* mdl) { return partials_stride(*mdl); }
 int64_t mopoe_wgrad_scratch_floats(const mopoe_model* mdl, const mopoe_step* st) {
     if (!mdl || !st || st->n < 1) return 0;
-    if (!st->backward) {   // mopoe_forward: sixteen pre-summed slabs, from 64 row groups on
+    if (!st->backward) {   // mopoe_forward: kFoldSlices pre-summed slabs, from 512 row groups on
         LatentLds L;
         step_layout(*mdl, *st, L);
-        return cdiv(st->n, L.rows) >= 4 * kFoldSlices ? (int64_t)kFoldSlices * partials_stride(*mdl) : 0;
+        return cdiv(st->n, L.rows) >= 8 * kFoldSlices ? (int64_t)kFoldSlices * partials_stride(*mdl) : 0;
     }
     if (!wgrad_big_step(*st)) return 0;
     KArgs ka;
@@ -2837,11 +2837,11 @@ int mopoe_forward(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buff
     if (int rc = launch_forward_part(ka, nullptr, s)) return rc;
     {
         ProfScope ps(MOPOE_KERNEL_FINALIZE, s);
-        // thousands of row groups (folded DAA inference): their slabs are summed in sixteen
+        // thousands of row groups (folded DAA inference): their slabs are summed in kFoldSlices (64)
         // slices by a launch of many blocks first -- the one finalising block walked 3,125
         // slabs in 27 us at 50,000 rows -- when the caller gave the scratch for it
         const int groups = cdiv(ka.st.n, ka.lds.rows);
-        if (buf->wgrad_scratch && groups >= 4 * kFoldSlices) {
+        if (buf->wgrad_scratch && groups >= 8 * kFoldSlices) {
             hipLaunchKernelGGL(k_partials_fold, dim3(cdiv(kStatStride, 256), kFoldSlices), dim3(256), 0, s,
                                (const float*)buf->partials, buf->wgrad_scratch, groups, ka.lds.part_stride);
             ka.buf.partials = buf->wgrad_scratch;

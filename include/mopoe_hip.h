@@ -277,7 +277,7 @@ typedef struct mopoe_buffers {
                                             weight gradients of a LARGE batch (the batch
                                             axis is split over workgroups, a second launch
                                             adds the parts in a fixed order) and, behind
-                                            them, sixteen pre-summed slabs of `partials`
+                                            them, 64 pre-summed slabs of `partials`
                                             (mopoe_forward: those slabs alone);
                                             NULL, or a step whose count is 0: the one-launch
                                             form                                          */
@@ -325,7 +325,7 @@ int mopoe_wfrag_floats(const mopoe_model* model);
 int mopoe_wfrag_refresh(const mopoe_model* model, const mopoe_buffers* buf, void* stream);
 /* floats of mopoe_buffers.wgrad_scratch this step would use (0: a training batch
  * below the size from which the split weight-gradient launches pay; a forward-only
- * step -- step->backward == 0 -- of fewer than 64 row groups) */
+ * step -- step->backward == 0 -- of fewer than 512 row groups) */
 int64_t mopoe_wgrad_scratch_floats(const mopoe_model* model, const mopoe_step* step);
 /* floats per row group in `partials` */
 int mopoe_partials_stride(const mopoe_model* model);

@@ -99,7 +99,7 @@ def test_split_form_agrees_with_the_one_launch_form_and_keeps_the_weight_copies(
     assert torch.is_tensor(wa.wgrad_scratch) and wb.wgrad_scratch is False
     scale = b.grads.abs().max().item()
     assert (a.grads - b.grads).abs().max().item() < 2e-6 * scale
-    # (the same forward; the split form adds the row groups' partial sums in sixteen slices
+    # (the same forward; the split form adds the row groups' partial sums in 64 slices
     #  first, the one-launch form walks them in one chain: float32 rounding of long sums)
     torch.testing.assert_close(wa.stats, wb.stats, rtol=5e-6, atol=1e-6)
     ref = a.wfrag.clone()
