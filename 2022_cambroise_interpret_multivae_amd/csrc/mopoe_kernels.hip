@@ -482,6 +482,10 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
 #define MOPOE_BIGK 32
 #endif
 constexpr int kBigRows = 64, kBigCols = 64, kBigK = MOPOE_BIGK, kBigLd = kBigK + 4;
+#ifndef MOPOE_BIG_BUFS
+#define MOPOE_BIG_BUFS 1
+#endif
+constexpr int kBigBufs = MOPOE_BIG_BUFS;   // LDS buffers per operand
 constexpr int kLinBigRows = 2048;  // batches from here on use the 64-row tiles
 
 // ROWS = 64: four waves, a 16 x 64 strip each.  (Measured and dropped: ROWS = 32 for batches of
@@ -510,8 +514,8 @@ __global__ __launch_bounds__(ROWS * 4) void k_linear_big(const LinArgs a_by_valu
     constexpr int PA = ROWS / RPP, PB = kBigCols / RPP;   // passes over the x rows / the W rows
     static_assert(PA >= 1 && PB >= 1 && ROWS % RPP == 0 && kBigCols % RPP == 0, "staging split");
     constexpr int LD = BF16 ? KC / 2 + 2 : KC + 4;        // LDS words per row (bf16: two k per word)
-    __shared__ __attribute__((aligned(16))) float As[2][ROWS * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][kBigCols * LD];
+    __shared__ __attribute__((aligned(16))) float As[kBigBufs][ROWS * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[kBigBufs][kBigCols * LD];
     __shared__ int rowsel[ROWS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(ROWS * 4) void k_linear_big(const LinArgs a_by_valu
     __syncthreads();
     const int nchunks = cdiv(K, KC);
     for (int c = 0; c < nchunks; ++c) {
-        const int cur = c & 1;
+        const int cur = kBigBufs == 1 ? 0 : c & 1;
         if (c + 1 < nchunks) fetch((c + 1) * KC);   // in flight under the MFMAs
         const float* Aw = &As[cur][(wave * 16) * LD];
         if constexpr (BF16) {
@@ -620,7 +624,12 @@ __global__ __launch_bounds__(ROWS * 4) void k_linear_big(const LinArgs a_by_valu
             }
         }
         if (c + 1 < nchunks) {
-            park(cur ^ 1);   // the other buffer was last read before the previous barrier
+            if constexpr (kBigBufs == 1) {
+                __syncthreads();   // (every wave is done reading the one buffer)
+                park(0);
+            } else {
+                park(cur ^ 1);   // the other buffer was last read before the previous barrier
+            }
             __syncthreads();
         }
     }
