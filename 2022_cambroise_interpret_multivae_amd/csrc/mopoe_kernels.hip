@@ -433,7 +433,15 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
     }
 }
 
-__global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
+// An instantiation per K split, at least MOPOE_LIN_MINW waves per SIMD: as ONE kernel with the
+// three splits inside and no such bound the compiler spread over 255 VGPRs + 40 AGPRs -- one wave
+// per SIMD, one workgroup per CU at a time, and every launch of 512 workgroups ran in two rounds
+// (1,024 rows: 16.0 us; the layers of a general topology: 10 us each).
+#ifndef MOPOE_LIN_MINW
+#define MOPOE_LIN_MINW 2
+#endif
+template <int KS>
+__global__ __launch_bounds__(256, MOPOE_LIN_MINW) void k_linear(const LinArgs a_by_value) {
     (void)a_by_value;  // read in place (see k_latent)
     const LinArgs& a = *(const LinArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -446,7 +454,7 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
         step_begin(a.counters, a.num_mods, a.publish ? &a.adam : nullptr);
     }
     const LinGroup& g = a.g[blockIdx.z];
-    const int ks = a.ksplit;
+    constexpr int ks = KS;
     if ((int)blockIdx.x * (64 / ks) >= g.ncols) return;
     // source row of each of the tile's 16 batch rows (a gather is resolved once)
     __shared__ int rowsel[kRows];
@@ -457,12 +465,7 @@ __global__ __launch_bounds__(256) void k_linear(const LinArgs a_by_value) {
     }
     GSTAMP(a.counters, kCtrStamp + 13, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
     const int* rs = gather ? rowsel : nullptr;
-    if (ks == 4)
-        linear_tile<4>(a, g, lds, rs, tid, lane, wave);
-    else if (ks == 2)
-        linear_tile<2>(a, g, lds, rs, tid, lane, wave);
-    else
-        linear_tile<1>(a, g, lds, rs, tid, lane, wave);
+    linear_tile<KS>(a, g, lds, rs, tid, lane, wave);
     GSTAMP(a.counters, kCtrStamp + 12, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
 }
 
@@ -1984,6 +1987,8 @@ struct Knobs {
     bool quad;           // MOPOE_QUAD=0 turns the four-row form off
     bool no_fuse;        // MOPOE_NO_FUSE: encoder layer and per-sample chain in two launches
     bool no_lean;        // MOPOE_NO_LEAN: the generic instantiation of the fused launch
+    int quad_max_n2;     // MOPOE_QUAD_MAX_N2: ... for steps with two decoder passes (1024: the encoder layer then a
+                         // launch of its own; configs[2] 58.0 -> 54.7 us)
     int q1_idle;         // MOPOE_Q1_IDLE: waves the four-row heads stage leaves free (2)
     int handoff_spins;   // MOPOE_TEST_HANDOFF_SPINS: polls of a row group before it gives up
     int fuse_blocks;     // MOPOE_FUSE_BLOCKS: largest grid the fused launch is used for (256)
@@ -2000,6 +2005,7 @@ Knobs read_knobs() {
     };
     Knobs k;
     k.quad_max_n = num("MOPOE_QUAD_MAX_N", 512);
+    k.quad_max_n2 = num("MOPOE_QUAD_MAX_N2", getenv("MOPOE_QUAD_MAX_N") ? k.quad_max_n : 1024);
     k.quad = num("MOPOE_QUAD", 1) != 0;
     k.no_fuse = getenv("MOPOE_NO_FUSE") != nullptr;
     k.no_lean = getenv("MOPOE_NO_LEAN") != nullptr;
@@ -2025,7 +2031,10 @@ int quad_first_pass_jobs(const mopoe_step& st) {   // jobs of the first decoder 
 bool quad_step(const mopoe_model& mdl, const mopoe_step& st) {
     if (!g_knobs.quad) return false;
     if (!st.backward || !st.sample || st.joint_mode != MOPOE_JOINT_MIXTURE || st.group_rows != 0 ||
-        st.rows_per_group != 0 || mdl.num_mods > 2 || st.num_jobs > 4 || st.n > quad_max_rows() || st.n < 4 ||
+        st.rows_per_group != 0 || mdl.num_mods > 2 || st.num_jobs > 4 || st.n < 4 ||
+        // (two decoder passes -- method poe -- gain more from four-row groups than one: measured,
+        //  Knobs::quad_max_n)
+        st.n > (st.num_jobs > quad_first_pass_jobs(st) ? g_knobs.quad_max_n2 : quad_max_rows()) ||
         cdiv(st.n, 4) > g_knobs.fuse_blocks ||   // (every row group resident: one per CU)
         st.likelihood != MOPOE_LIK_NORMAL)
         return false;
@@ -2197,8 +2206,13 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s, 
     la.ksplit = ks;
     {
         ProfScope ps(MOPOE_KERNEL_LINEAR, s);
-        hipLaunchKernelGGL(k_linear, dim3(cdiv(max_cols, 64 / ks), cdiv(la.n, kRows), la.ngroups),
-                           dim3(256), lds, s, la);
+        const dim3 grid(cdiv(max_cols, 64 / ks), cdiv(la.n, kRows), la.ngroups);
+        if (ks == 4)
+            hipLaunchKernelGGL(k_linear<4>, grid, dim3(256), lds, s, la);
+        else if (ks == 2)
+            hipLaunchKernelGGL(k_linear<2>, grid, dim3(256), lds, s, la);
+        else
+            hipLaunchKernelGGL(k_linear<1>, grid, dim3(256), lds, s, la);
     }
     return check_launch("k_linear");
 }

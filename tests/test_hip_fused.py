@@ -46,10 +46,10 @@ def test_fused_launch_is_bit_identical_to_three_launches(n, monkeypatch):
                                       (256, "poe"), (37, "poe"), (512, "joint_elbo"), (400, "poe"),
                                       (768, "joint_elbo"), (1024, "poe")])
 def test_four_row_groups_are_deterministic_and_track_the_three_launches(n, method, monkeypatch):
-    """The four-row form (batches of <= 512 rows, <= 2 modalities; one decoder pass, or method
-    poe's two; up to 1,024 rows on request -- MOPOE_QUAD_MAX_N -- where the encoder layer
-    becomes a launch of its own in front of a fused launch of row groups only) is the same
-    step with other summation orders: bit-identical from run to run
+    """The four-row form (<= 2 modalities; one decoder pass up to 512 rows, method poe's two up
+    to 1,024 -- beyond 512 rows, or on request (MOPOE_QUAD_MAX_N), the encoder layer becomes a
+    launch of its own in front of a fused launch of row groups only) is the same step with
+    other summation orders: bit-identical from run to run
     (3000 steps, no hand-off times out, the fragment-major weight copies follow every update;
     the two LDS adds per element of its fusion backward commute), and within float32 rounding
     of the three-launch form while rounding has had no time to grow."""

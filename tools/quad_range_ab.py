@@ -12,7 +12,7 @@ import mopoe_amd as mm  # noqa: E402
 
 
 def run(method, n, env):
-    for k in ("MOPOE_QUAD", "MOPOE_QUAD_MAX_N", "MOPOE_FUSE_BLOCKS", "MOPOE_LIN_BIG_ROWS", "MOPOE_LIN_KS"):
+    for k in ("MOPOE_QUAD", "MOPOE_QUAD_MAX_N", "MOPOE_FUSE_BLOCKS", "MOPOE_QUAD_MAX_N2", "MOPOE_LIN_BIG_ROWS", "MOPOE_LIN_KS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     mm._lib.reload_knobs()          # (the library reads its environment once)
@@ -45,8 +45,6 @@ def run(method, n, env):
 
 
 for rnd in range(2):
-    for method, n in (("poe", 512), ("poe", 1024), ("joint_elbo", 384), ("joint_elbo", 512), ("joint_elbo", 640),
-                      ("joint_elbo", 768), ("joint_elbo", 1024)):
-        run(method, n, {"MOPOE_QUAD_MAX_N": "256"})     # sixteen-row groups, producers in the launch
-        run(method, n, {"MOPOE_QUAD_MAX_N": "1024"})    # four-row groups (the encoder layer a launch of its own
-                                                        # where the producers do not fit beside them)
+    for method, n in (("poe", 576), ("poe", 640), ("poe", 768), ("poe", 1024)):
+        run(method, n, {"MOPOE_QUAD_MAX_N": "512"})     # sixteen-row groups beyond 512 rows
+        run(method, n, {})                              # two decoder passes: four-row groups up to 1,024 rows
