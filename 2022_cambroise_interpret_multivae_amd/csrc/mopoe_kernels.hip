@@ -506,8 +506,11 @@ DEV uint32_t bf16_pair(float lo, float hi) {   // two roundings to nearest even,
     return (a >> 16) | (b & 0xFFFF0000u);
 }
 
+#ifndef MOPOE_LB_MINW
+#define MOPOE_LB_MINW 1
+#endif
 template <int ROWS, bool BF16>
-__global__ __launch_bounds__(ROWS * 4) void k_linear_big(const LinArgs a_by_value) {
+__global__ __launch_bounds__(ROWS * 4, MOPOE_LB_MINW) void k_linear_big(const LinArgs a_by_value) {
     (void)a_by_value;  // read in place (see k_latent)
     const LinArgs& a = *(const LinArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int T = ROWS * 4;                  // threads: a wave per 16-row strip

@@ -1,5 +1,5 @@
 #!/bin/bash
-for lib in libmopoe_hip.so libmopoe_hip_vLB1.so libmopoe_hip_vLB1k64.so libmopoe_hip.so libmopoe_hip_vLB1.so libmopoe_hip_vLB1k64.so; do
+for lib in libmopoe_hip.so libmopoe_hip_vWBc18.so libmopoe_hip_vWBc24.so libmopoe_hip.so libmopoe_hip_vWBc18.so libmopoe_hip_vWBc24.so; do
 MOPOE_LIB=$lib python - <<'PY'
 import os, sys, torch
 sys.path.insert(0, ".")
