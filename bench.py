@@ -189,6 +189,10 @@ def roofline_of(spec, n, prof, dt_per_step, fused_adam, world, traffic="C1"):
     avg_us = {k: v - overhead_us for k, v in raw_us.items()}
     avg_s = avg_us[name] * 1e-6
     km = models[name]
+    if name == "k_fused" and prof.get("k_linear", (0, 0))[0]:
+        # (row groups only: the encoder layer ran as a launch of its own in front of them --
+        #  four-row groups beyond 512 rows -- so its work is not this launch's)
+        km = models["k_latent"]
     t_mfma = km["flops"] / (PEAK_F32_MFMA_TFLOPS * 1e12)
     t_hbm = km["bytes"] / (PEAK_HBM_GBS * 1e9)
     if t_mfma >= t_hbm:
