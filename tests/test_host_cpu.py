@@ -196,7 +196,7 @@ def test_hot_kernels_keep_their_registers_and_scratch():
                              sgpr_spill=get("SGPRs Spill"), occupancy=get("Occupancy [waves/SIMD]"))
     pick = lambda frag: next(v for k, v in kernels.items() if frag in k)
     lean, generic = pick("k_fusedILi1EE"), pick("k_fusedILi0EE")
-    latent, linear = pick("k_latentILi0EE"), pick("8k_linearE")
+    latent = pick("k_latentILi0EE")
     # (measured builds of the lean launch: 24..80 bytes of scratch all ran within 1 % of each
     #  other; 112 bytes and more cost a microsecond)
     assert lean["vgpr"] <= 128 and lean["scratch"] <= 96 and lean["occupancy"] >= 4, lean
@@ -210,7 +210,12 @@ def test_hot_kernels_keep_their_registers_and_scratch():
     assert latent["vgpr"] <= 128 and latent["scratch"] == 0, latent
     for frag in ("k_latentILi1EE", "k_latentILi2EE", "k_latentILi3EE"):   # large batches: the specialised bodies
         assert pick(frag)["vgpr"] <= 128 and pick(frag)["scratch"] <= 64, (frag, pick(frag))
-    assert linear["scratch"] == 0, linear
+    # the separate encoder-layer launch: an instantiation per K split, TWO waves per SIMD (as one
+    # kernel without the bound it took 255 VGPRs + 40 AGPRs: one wave per SIMD, every launch in
+    # two rounds -- DESIGN.md section 5.5)
+    for frag in ("8k_linearILi1EE", "8k_linearILi2EE", "8k_linearILi4EE"):
+        assert pick(frag)["occupancy"] >= 2 and pick(frag)["scratch"] <= 16, (frag, pick(frag))
+    assert pick("k_wgrad_bigE")["occupancy"] >= 7 and pick("k_wgrad_bigE")["scratch"] == 0
     for frag in ("k_wgradILi4ELb0", "k_wgradILi8ELb0", "k_wgradILi4ELb1", "k_wgradILi8ELb1",
                  "k_adamE", "k_xgmiE", "k_linear_bigILi64ELb0EE", "k_linear_bigILi64ELb1EE"):
         assert pick(frag)["scratch"] == 0, (frag, pick(frag))
