@@ -1982,16 +1982,17 @@ void bind_buffers(KArgs& ka, const mopoe_buffers& buf) {
 // kernels between two steps of one run.  mopoe_reload_knobs() re-reads them (the tests that
 // compare launch forms inside one process call it after changing the environment).
 struct Knobs {
-    int quad_max_n;      // MOPOE_QUAD_MAX_N: rows up to which the four-row form is used (512; at most 1024:
-                         // one group per CU.  Measured, us per step, sixteen-row / four-row groups: joint_elbo
-                         // 384 rows 38.1 / 32.9, 512: 39.2 / 37.1, 640: 43.0 / 46.6, 768: 46.3 / 51.9,
-                         // 1024: 46.6 / 49.9; poe 512: 50.2 / 44.1, 1024: 58.3 / 57.6 -- from 640 rows on the
-                         // producers of the four-row grid are 256-column blocks, or a launch of their own)
+    int quad_max_n;      // MOPOE_QUAD_MAX_N: rows up to which the four-row form is used (1024 = one group per CU).
+                         // Measured, us per step, sixteen-row / four-row groups (beyond 512 rows the launch has
+                         // more blocks than CUs: launch_forward_part): joint_elbo 384 rows 38.1 / 32.9, 512:
+                         // 39.2 / 37.1, 640: 43.2 / 42.0, 768: 46.5 / 42.1, 1024: 46.8 / 46.0; poe 512:
+                         // 50.2 / 44.1, 640: 53.2 / 48.4, 768: 56.5 / 47.8, 1024: 58.0 / 53.4
     bool quad;           // MOPOE_QUAD=0 turns the four-row form off
     bool no_fuse;        // MOPOE_NO_FUSE: encoder layer and per-sample chain in two launches
     bool no_lean;        // MOPOE_NO_LEAN: the generic instantiation of the fused launch
-    int quad_max_n2;     // MOPOE_QUAD_MAX_N2: ... for steps with two decoder passes (1024: the encoder layer then a
-                         // launch of its own; configs[2] 58.0 -> 54.7 us)
+    int quad_oversub;    // MOPOE_QUAD_OVERSUB: K parts of the producers of an over-subscribed four-row launch
+                         // (-1: the launch code's rule, 0: never)
+    int quad_max_n2;     // MOPOE_QUAD_MAX_N2: ... for steps with two decoder passes (method poe; follows MOPOE_QUAD_MAX_N)
     int q1_idle;         // MOPOE_Q1_IDLE: waves the four-row heads stage leaves free (2)
     int handoff_spins;   // MOPOE_TEST_HANDOFF_SPINS: polls of a row group before it gives up
     int fuse_blocks;     // MOPOE_FUSE_BLOCKS: largest grid the fused launch is used for (256)
@@ -2007,7 +2008,8 @@ Knobs read_knobs() {
         return v ? (int)strtol(v, nullptr, 0) : dflt;
     };
     Knobs k;
-    k.quad_max_n = num("MOPOE_QUAD_MAX_N", 512);
+    k.quad_oversub = num("MOPOE_QUAD_OVERSUB", -1);
+    k.quad_max_n = num("MOPOE_QUAD_MAX_N", 1024);
     k.quad_max_n2 = num("MOPOE_QUAD_MAX_N2", getenv("MOPOE_QUAD_MAX_N") ? k.quad_max_n : 1024);
     k.quad = num("MOPOE_QUAD", 1) != 0;
     k.no_fuse = getenv("MOPOE_NO_FUSE") != nullptr;
@@ -2308,7 +2310,27 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         for (int z = 0; z < la.ngroups; ++z) n += (narrow(z) ? 1 : ks) * row_tiles;
         return n;
     };
-    while (hd.ks > 1 && nlin_for(hd.ks) + groups > fuse_blocks()) hd.ks /= 2;
+    // Four-row groups whose producers do not fit the chip beside them in 64-column blocks stay in
+    // ONE launch of more blocks than CUs: the producers have the lower block numbers, so every
+    // one of them holds a CU before the first row group starts to wait (no circular wait), and
+    // the row groups take the CUs the producers leave.  K parts: as many as keep the launch
+    // within 1.8 x the CUs (measured: method poe, 768 rows, 4 parts = 432 blocks 48.0 us, 2 parts
+    // 51.3, the encoder layer as a launch of its own 52.6; 1,024 rows, 4 parts = 576 blocks 55.5,
+    // 2 parts = 448 blocks 53.5, own launch 54.1).  MOPOE_QUAD_OVERSUB: -1 this rule, 0 never, k parts.
+    int oversub_ks = 0;
+    if (quad && groups <= fuse_blocks() && nlin_for(4) + groups > fuse_blocks()) {
+        if (g_knobs.quad_oversub > 0) oversub_ks = g_knobs.quad_oversub;
+        if (g_knobs.quad_oversub < 0)
+            for (int k = 4; k >= 1 && !oversub_ks; k /= 2)
+                if (5 * (nlin_for(k) + groups) <= 9 * fuse_blocks()) oversub_ks = k;
+    }
+    // (only where it buys more K parts than the launch that fits has)
+    int fit_ks = 4;
+    while (fit_ks > 1 && nlin_for(fit_ks) + groups > fuse_blocks()) fit_ks /= 2;
+    // (two parts that fit are as good: 576 rows 46.9 / 47.5 us)
+    const bool oversub = oversub_ks > 0 && (nlin_for(fit_ks) + groups > fuse_blocks() || (fit_ks == 1 && oversub_ks > 1));
+    if (oversub) hd.ks = oversub_ks;
+    while (hd.ks > 1 && !oversub && nlin_for(hd.ks) + groups > fuse_blocks()) hd.ks /= 2;
     int nlin = nlin_for(hd.ks);
     int blocks_per_tile[MOPOE_MAX_MODS];
     for (int z = 0; z < MOPOE_MAX_MODS; ++z) {
@@ -2327,7 +2349,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
                     worst = z;
                 }
             if (worst < 0 || hd.tiles[worst] != 4 || la.g[worst].K < 64 ||
-                nlin + 4 * row_tiles + groups > fuse_blocks())
+                oversub || nlin + 4 * row_tiles + groups > fuse_blocks())
                 break;
             hd.tiles[worst] = 2;
             blocks_per_tile[worst] = 8;
@@ -2344,7 +2366,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     // Four-row groups whose producers would not fit the chip beside them (257..1024 rows): the
     // encoder layer runs as a launch of its own and the fused launch is row groups only --
     // all of them resident, one per CU, where sixteen-row groups would use a quarter of the CUs
-    const bool quad_split = quad && ka.st.group_rows == 0 && nlin + groups > fuse_blocks() &&
+    const bool quad_split = quad && !oversub && ka.st.group_rows == 0 && nlin + groups > fuse_blocks() &&
                             groups <= fuse_blocks() && !no_fuse();
     if (quad_split) {
         if (int rc = launch_linear(la, maxd, kHid, s, 0)) return rc;   // (bumps the step counter, publishes Adam's records)
@@ -2355,7 +2377,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         hd.producers = 0;
         hd.nlin = nlin = 0;
     }
-    if ((ka.lds.rows == kRows || quad) && ka.st.group_rows == 0 && nlin + groups <= fuse_blocks() && !no_fuse()) {
+    if ((ka.lds.rows == kRows || quad) && ka.st.group_rows == 0 && (nlin + groups <= fuse_blocks() || oversub) && !no_fuse()) {
         static thread_local int lds_opted_f = 0;
         const int kp = round_up(maxd < kEncKChunk ? maxd : kEncKChunk, 16);
         const int lin_lds = (kRows + kRows * (kp + 4) + 4 * kRows * 68) * (int)sizeof(float);   // (>= kRows * 260)

@@ -332,7 +332,7 @@ int mopoe_partials_stride(const mopoe_model* model);
 /* row groups the fused per-sample kernel cuts the batch into for this step
  * (= the number of partial slabs the caller provides): ceil(n / rows), rows = 16
  * unless the LDS carve-up asks for fewer, step->rows_per_group pins it, or the step
- * runs in four-row groups (training batches of 4..512 rows, <= 2 modalities) */
+ * runs in four-row groups (training batches of 4..1024 rows, <= 2 modalities) */
 int mopoe_row_groups(const mopoe_model* model, const mopoe_step* step);
 /* bytes of LDS the fused latent kernel needs for this model and step (<= 160 KiB
  * after the rows-per-group fallback; larger only if even one row does not fit) */

@@ -44,19 +44,16 @@ def test_fused_launch_is_bit_identical_to_three_launches(n, monkeypatch):
 @pytest.mark.parametrize("n,method", [(256, "joint_elbo"), (100, "joint_elbo"), (16, "joint_elbo"),
                                       (5, "joint_elbo"), (4, "joint_elbo"),
                                       (256, "poe"), (37, "poe"), (512, "joint_elbo"), (400, "poe"),
-                                      (768, "joint_elbo"), (1024, "poe")])
+                                      (768, "joint_elbo"), (1024, "poe"), (640, "poe")])
 def test_four_row_groups_are_deterministic_and_track_the_three_launches(n, method, monkeypatch):
-    """The four-row form (<= 2 modalities; one decoder pass up to 512 rows, method poe's two up
-    to 1,024 -- beyond 512 rows, or on request (MOPOE_QUAD_MAX_N), the encoder layer becomes a
-    launch of its own in front of a fused launch of row groups only) is the same step with
-    other summation orders: bit-identical from run to run
+    """The four-row form (<= 2 modalities, up to 1,024 rows; beyond 512 rows its launch has more
+    blocks than CUs -- the producers first, the row groups on the CUs they leave) is the same
+    step with other summation orders: bit-identical from run to run
     (3000 steps, no hand-off times out, the fragment-major weight copies follow every update;
     the two LDS adds per element of its fusion backward commute), and within float32 rounding
     of the three-launch form while rounding has had no time to grow."""
     monkeypatch.delenv("MOPOE_NO_FUSE", raising=False)
     monkeypatch.delenv("MOPOE_QUAD", raising=False)
-    if n > 512:
-        monkeypatch.setenv("MOPOE_QUAD_MAX_N", "1024")
     quad = _train(3000, 5, n, method)
     again = _train(3000, 5, n, method)
     for a, b in zip(quad, again):

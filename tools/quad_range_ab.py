@@ -12,7 +12,7 @@ import mopoe_amd as mm  # noqa: E402
 
 
 def run(method, n, env):
-    for k in ("MOPOE_QUAD", "MOPOE_QUAD_MAX_N", "MOPOE_FUSE_BLOCKS", "MOPOE_QUAD_MAX_N2", "MOPOE_LIN_BIG_ROWS", "MOPOE_LIN_KS"):
+    for k in ("MOPOE_QUAD", "MOPOE_QUAD_MAX_N", "MOPOE_FUSE_BLOCKS", "MOPOE_QUAD_MAX_N2", "MOPOE_QUAD_OVERSUB", "MOPOE_LIN_BIG_ROWS", "MOPOE_LIN_KS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     mm._lib.reload_knobs()          # (the library reads its environment once)
@@ -45,6 +45,8 @@ def run(method, n, env):
 
 
 for rnd in range(2):
-    for method, n in (("poe", 576), ("poe", 640), ("poe", 768), ("poe", 1024)):
-        run(method, n, {"MOPOE_QUAD_MAX_N": "512"})     # sixteen-row groups beyond 512 rows
-        run(method, n, {})                              # two decoder passes: four-row groups up to 1,024 rows
+    for method, n in (("poe", 576), ("poe", 640), ("poe", 768), ("poe", 1024), ("joint_elbo", 576), ("joint_elbo", 640),
+                      ("joint_elbo", 768), ("joint_elbo", 1024)):
+        run(method, n, {"MOPOE_QUAD_MAX_N": "512"})                               # sixteen-row groups
+        run(method, n, {"MOPOE_QUAD_MAX_N": "1024", "MOPOE_QUAD_OVERSUB": "0"})   # four-row groups: fit, or the encoder layer apart
+        run(method, n, {"MOPOE_QUAD_MAX_N": "1024"})                              # four-row groups: more blocks than CUs
