@@ -70,6 +70,28 @@ def test_four_row_groups_are_deterministic_and_track_the_three_launches(n, metho
     assert (short[1] - plain[1]).abs().max().item() < 1e-3 * plain[1].abs().max().item()
 
 
+def test_four_row_groups_behind_an_encoder_layer_launch_of_its_own(monkeypatch):
+    """MOPOE_QUAD_OVERSUB=0: beyond 512 rows the encoder layer runs as a launch of its own and
+    the fused launch holds row groups only (no producers: the hand-off word is never raised
+    and never waited for).  Deterministic, and within float32 rounding of the three launches."""
+    monkeypatch.delenv("MOPOE_NO_FUSE", raising=False)
+    monkeypatch.delenv("MOPOE_QUAD", raising=False)
+    monkeypatch.setenv("MOPOE_QUAD_OVERSUB", "0")
+    split = _train(1000, 5, 768, "poe")
+    again = _train(1000, 5, 768, "poe")
+    for a, b in zip(split, again):
+        assert torch.equal(a, b)
+    short = _train(20, 5, 768, "poe")
+    monkeypatch.delenv("MOPOE_QUAD_OVERSUB")
+    one_launch = _train(1000, 5, 768, "poe")
+    assert not torch.equal(split[0], one_launch[0])         # (another order of the encoder layer's sums)
+    monkeypatch.setenv("MOPOE_QUAD", "0")
+    monkeypatch.setenv("MOPOE_NO_FUSE", "1")
+    plain = _train(20, 5, 768, "poe")
+    assert (short[0] - plain[0]).abs().max().item() < 2e-4
+    assert (short[1] - plain[1]).abs().max().item() < 1e-3 * plain[1].abs().max().item()
+
+
 SHAPES = {
     # BASELINE configs[2]: method poe -> the two-pass form of the fused launch
     "C3_poe_bs1024": dict(names=["clinical", "rois"], dims=[7, 444], style=[3, 20], method="poe",
