@@ -1998,6 +1998,7 @@ struct Knobs {
     int fuse_blocks;     // MOPOE_FUSE_BLOCKS: largest grid the fused launch is used for (256)
     int knock;           // MOPOE_KNOCK (diagnostic build): phases to leave out
     bool wgrad_nofold, wgrad_tall;   // MOPOE_WGRAD_NOFOLD / MOPOE_WGRAD_TALL: experiments
+    int wb_min_rows;     // MOPOE_WB_MIN_ROWS: rows from which the weight gradients run as split 64 x 64 tiles (kWbMinRows)
     int lin_ks;          // MOPOE_LIN_KS: K parts of the separate encoder-layer launch (0: its own choice; experiments)
     int lin_big_rows;    // MOPOE_LIN_BIG_ROWS: rows from which the encoder layer runs in 64 x 64 tiles (kLinBigRows)
     int xg_fail_slot;    // MOPOE_TEST_XG_FAIL_SLOT: the exchanging block that reports a failed wait (-1)
@@ -2017,6 +2018,7 @@ Knobs read_knobs() {
     k.q1_idle = num("MOPOE_Q1_IDLE", 2);
     k.lin_big_rows = num("MOPOE_LIN_BIG_ROWS", kLinBigRows);
     k.lin_ks = num("MOPOE_LIN_KS", 0);
+    k.wb_min_rows = num("MOPOE_WB_MIN_ROWS", 4096);   // (= kWbMinRows, mopoe_wgrad_big.inc)
     k.handoff_spins = num("MOPOE_TEST_HANDOFF_SPINS", kHandoffSpins);
     k.fuse_blocks = num("MOPOE_FUSE_BLOCKS", 256);
     k.knock = num("MOPOE_KNOCK", 0);
