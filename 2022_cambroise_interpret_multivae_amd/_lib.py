@@ -6,16 +6,26 @@ object is missing or exports the wrong ABI this module raises at import time.
 import ctypes as C
 import os
 
-import torch  # noqa: F401  (loads the ROCm runtime the library binds to)
+# Host-side waits.  A training step here is ~30 us of GPU work: when the host does wait for the
+# GPU (torch.cuda.synchronize, a blocking copy) ROCm's default -- sleep until an interrupt --
+# costs 20-60 us per wait, polling ~5 us (HSA_ENABLE_INTERRUPT=0; the runtime reads it once, when
+# it starts, i.e. at the process's first HIP call -- importing this package before that is
+# enough).  The package asks for polling unless the user decided otherwise: an explicit
+# HSA_ENABLE_INTERRUPT wins, MOPOE_HOST_WAIT=interrupt keeps ROCm's default.  bench.py and
+# run_epochs.train therefore wait the same way (bench.py reports it as config.host_wait).
+if os.environ.get("MOPOE_HOST_WAIT", "poll") != "interrupt":
+    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+
+import torch  # noqa: E402,F401  (loads the ROCm runtime the library binds to)
 
 MAX_MODS = 5
 MAX_SUBSETS = 31
 MAX_JOBS = 10
 HIDDEN = 256
 ROWS = 16
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_RANKS = 8
-IPC_HANDLE_BYTES = 64
+IPC_HANDLE_BYTES = 80
 RCCL_ID_BYTES = 128
 MAX_LAYERS = 4
 
@@ -126,6 +136,7 @@ class Buffers(C.Structure):
         ("wfrag", _ptr),
         ("partials", _ptr),
         ("wgrad_scratch", _ptr),
+        ("wgrad_scratch_floats", C.c_int64),
     ]
 
 
@@ -215,6 +226,7 @@ SYMBOLS = {
     "mopoe_rccl_train_step": (C.c_int, [_ptr, C.POINTER(Model), C.POINTER(Step),
                                         C.POINTER(Buffers), C.POINTER(Adam), _ptr]),
     "mopoe_rccl_allreduce": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr]),
+    "mopoe_rccl_info": (C.c_int, [_ptr, C.POINTER(_i32), C.POINTER(_i32)]),
     "mopoe_rccl_destroy": (C.c_int, [_ptr]),
     "mopoe_linear": (C.c_int, [_ptr, _i32, _i32, _ptr, _ptr, _i32, _i32, _ptr,
                                _ptr]),

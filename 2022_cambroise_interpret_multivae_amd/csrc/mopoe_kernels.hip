@@ -19,6 +19,7 @@
 // The math follows SURVEY.md Appendix A; reference file:line citations are in
 // include/mopoe_hip.h and DESIGN.md.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <math.h>
 #include <stddef.h>
 #include <stdio.h>
@@ -1995,7 +1996,10 @@ struct Knobs {
     int quad_max_n2;     // MOPOE_QUAD_MAX_N2: ... for steps with two decoder passes (method poe; follows MOPOE_QUAD_MAX_N)
     int q1_idle;         // MOPOE_Q1_IDLE: waves the four-row heads stage leaves free (2)
     int handoff_spins;   // MOPOE_TEST_HANDOFF_SPINS: polls of a row group before it gives up
-    int fuse_blocks;     // MOPOE_FUSE_BLOCKS: largest grid the fused launch is used for (256)
+    int fuse_blocks;     // MOPOE_FUSE_BLOCKS: largest grid the fused launch is used for; 0 (default): the
+                         // compute units of the device the call runs on (256 on a whole MI355X)
+    bool cu_mask;        // a CU mask is in force (HSA_CU_MASK / ROC_GLOBAL_CU_MASK / HSA_CU_MASK_SKIP_INIT in the
+                         // environment): how many workgroups are resident at once is not known -- no fused launch
     int knock;           // MOPOE_KNOCK (diagnostic build): phases to leave out
     bool wgrad_nofold, wgrad_tall;   // MOPOE_WGRAD_NOFOLD / MOPOE_WGRAD_TALL: experiments
     int wb_min_rows;     // MOPOE_WB_MIN_ROWS: rows from which the weight gradients run as split 64 x 64 tiles (kWbMinRows)
@@ -2020,7 +2024,8 @@ Knobs read_knobs() {
     k.lin_ks = num("MOPOE_LIN_KS", 0);
     k.wb_min_rows = num("MOPOE_WB_MIN_ROWS", 4096);   // (= kWbMinRows, mopoe_wgrad_big.inc)
     k.handoff_spins = num("MOPOE_TEST_HANDOFF_SPINS", kHandoffSpins);
-    k.fuse_blocks = num("MOPOE_FUSE_BLOCKS", 256);
+    k.fuse_blocks = num("MOPOE_FUSE_BLOCKS", 0);
+    k.cu_mask = getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK") || getenv("HSA_CU_MASK_SKIP_INIT");
     k.knock = num("MOPOE_KNOCK", 0);
     k.wgrad_nofold = getenv("MOPOE_WGRAD_NOFOLD") != nullptr;
     k.wgrad_tall = getenv("MOPOE_WGRAD_TALL") != nullptr;
@@ -2028,6 +2033,42 @@ Knobs read_knobs() {
     return k;
 }
 Knobs g_knobs = read_knobs();
+
+// The fused launch's hand-off (row groups wait for producer workgroups of the SAME grid) is free
+// of circular waits only while every producer holds a compute unit before a row group starts
+// to wait.  What the launch code may assume about that:
+//   device_cus()   the compute units of the device this thread's calls go to
+//                  (hipDeviceAttributeMultiprocessorCount, asked once per device) -- NOT the
+//                  constant 256: a partitioned MI355X (CPX: 32) or another part has fewer;
+//   fuse_blocks()  the workgroups of 1,024 threads taken to be resident at once: that count,
+//                  or MOPOE_FUSE_BLOCKS;
+//   no_fuse()      MOPOE_NO_FUSE, a CU mask in the environment, or a connected peer-window
+//                  communicator whose ranks share this device (g_shared_device_comms): other
+//                  processes' grids on the same CUs break residency.
+// launch_forward_part additionally holds the producers of an over-subscribed launch to
+// hipOccupancyMaxActiveBlocksPerMultiprocessor x device_cus() (resident_blocks).
+// HIP does not promise dispatch in block-index order; the order is what the hardware does on
+// an exclusive device (soaked: profiles/r03_n_soak_oversubscribed_100k_steps.txt), the bounded
+// wait + sticky invalid word + StepRetry turn a violation into a retried step, not a hang.
+int device_cus() {
+    static thread_local int cached_dev = -1, cached_cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;     // (no device: layout queries on a CPU host)
+    if (dev != cached_dev) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) return 256;
+        cached_dev = dev;
+        cached_cus = v;
+    }
+    return cached_cus;
+}
+// connected peer-window communicators of this process whose ranks share this rank's device
+// (mopoe_comm_connect / mopoe_comm_destroy): while there is one, EVERY step of the process runs in
+// separate launches -- also the steps that do not pass the communicator (the exchange as a
+// launch of its own behind mopoe_train_step)
+std::atomic<int> g_shared_device_comms{0};
+static bool no_fuse() { return g_knobs.no_fuse || g_knobs.cu_mask || g_shared_device_comms.load(std::memory_order_relaxed) > 0; }
+static int fuse_blocks() { return g_knobs.fuse_blocks > 0 ? g_knobs.fuse_blocks : device_cus(); }
 
 int quad_max_rows() { return g_knobs.quad_max_n; }
 int quad_first_pass_jobs(const mopoe_step& st) {   // jobs of the first decoder pass (slot)
@@ -2042,7 +2083,7 @@ bool quad_step(const mopoe_model& mdl, const mopoe_step& st) {
         // (two decoder passes -- method poe -- gain more from four-row groups than one: measured,
         //  Knobs::quad_max_n)
         st.n > (st.num_jobs > quad_first_pass_jobs(st) ? g_knobs.quad_max_n2 : quad_max_rows()) ||
-        cdiv(st.n, 4) > g_knobs.fuse_blocks ||   // (every row group resident: one per CU)
+        cdiv(st.n, 4) > fuse_blocks() ||   // (every row group resident: one per CU)
         st.likelihood != MOPOE_LIK_NORMAL)
         return false;
     for (int k = 0; k < st.num_subsets; ++k)
@@ -2058,7 +2099,7 @@ bool quad_step(const mopoe_model& mdl, const mopoe_step& st) {
                 return false;
         }
     }
-    return !g_knobs.no_fuse && !g_knobs.no_lean;
+    return !no_fuse() && !g_knobs.no_lean;
 }
 // THE layout of a step: every caller (launches, mopoe_row_groups, mopoe_latent_lds_bytes)
 // goes through here, so they agree on the rows per group
@@ -2227,12 +2268,10 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s, 
 // MOPOE_NO_FUSE=1 keeps the encoder layer and the per-sample chain in two launches;
 // MOPOE_FUSE_BLOCKS caps the grid the fused launch is used for (Knobs: read once; a test
 // that compares the two forms inside one process calls mopoe_reload_knobs in between).
-static bool no_fuse() { return g_knobs.no_fuse; }
 // MOPOE_TEST_HANDOFF_SPINS: a test knob -- with 0 every row group of the fused launch gives
 // up without looking at its flag, which is how tests/test_hip_invalid.py drives the "step
 // could not be completed" path (flags left non-zero by the producers included).
 static int handoff_spins() { return g_knobs.handoff_spins; }
-static int fuse_blocks() { return g_knobs.fuse_blocks; }
 
 // Which instantiation of the fused launch serves this step (latent_body's FORM); 0 = the
 // generic one.  MOPOE_NO_LEAN=1 forces the generic form (the forms are bit-identical:
@@ -2251,6 +2290,37 @@ int launch_form(const KArgs& ka) {
     if (mdl.num_mods <= 2 && !L.single_pass && L.s3_nt == 2 && L.xs_early && st.num_jobs <= 4) return 2;
     if (mdl.num_mods <= 4 && L.single_pass && L.s3_nt == 4 && !L.xs_early && st.num_jobs <= 4) return 3;
     return 0;
+}
+
+const void* fused_form_fn(int form) {
+    switch (form) {
+        case 1: return reinterpret_cast<const void*>(k_fused<1>);
+        case 2: return reinterpret_cast<const void*>(k_fused<2>);
+        case 3: return reinterpret_cast<const void*>(k_fused<3>);
+        case 4: return reinterpret_cast<const void*>(k_fused<4>);
+        case 5: return reinterpret_cast<const void*>(k_fused<5>);
+        default: return reinterpret_cast<const void*>(k_fused<0>);
+    }
+}
+// Workgroups of the fused launch (instantiation `form`, `lds` bytes of dynamic LDS) that are
+// resident at once on the current device: hipOccupancyMaxActiveBlocksPerMultiprocessor x its
+// compute units.  Asked once per (device, form, LDS size) and thread.
+int resident_blocks(int form, int lds) {
+    struct Key { int dev, form, lds, blocks; };
+    static thread_local Key cache[8] = {};
+    static thread_local int used = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    for (int i = 0; i < used; ++i)
+        if (cache[i].dev == dev && cache[i].form == form && cache[i].lds == lds) return cache[i].blocks;
+    int per_cu = 0;
+    if (lds > 64 * 1024)   // (the query honours the opt-in the launch makes as well)
+        (void)hipFuncSetAttribute(fused_form_fn(form), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_form_fn(form), kLatentThreads, (size_t)lds) != hipSuccess)
+        per_cu = 0;
+    const int blocks = per_cu * device_cus();
+    if (used < 8) cache[used++] = Key{dev, form, lds, blocks};
+    return blocks;
 }
 
 int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) {
@@ -2330,7 +2400,18 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     int fit_ks = 4;
     while (fit_ks > 1 && nlin_for(fit_ks) + groups > fuse_blocks()) fit_ks /= 2;
     // (two parts that fit are as good: 576 rows 46.9 / 47.5 us)
-    const bool oversub = oversub_ks > 0 && (nlin_for(fit_ks) + groups > fuse_blocks() || (fit_ks == 1 && oversub_ks > 1));
+    bool oversub = oversub_ks > 0 && (nlin_for(fit_ks) + groups > fuse_blocks() || (fit_ks == 1 && oversub_ks > 1));
+    if (oversub) {
+        // ... and only while every PRODUCER is resident before the first row group waits: on the
+        // device the call runs on, by the runtime's own occupancy figure for this kernel and
+        // LDS size (not the constant 256).  Otherwise: the encoder layer as a launch of its own
+        // in front of the row groups (quad_split below) -- same bits (tests/test_hip_fused.py)
+        const int kp0 = round_up(maxd < kEncKChunk ? maxd : kEncKChunk, 16);
+        const int lin_lds0 = (kRows + kRows * (kp0 + 4) + 4 * kRows * 68) * (int)sizeof(float);
+        const int resident = resident_blocks(ka.lds.single_pass ? 4 : 5, lds > lin_lds0 ? lds : lin_lds0);
+        const int cap = resident < fuse_blocks() ? resident : fuse_blocks();
+        if (nlin_for(oversub_ks) > cap || groups > cap) oversub = false;
+    }
     if (oversub) hd.ks = oversub_ks;
     while (hd.ks > 1 && !oversub && nlin_for(hd.ks) + groups > fuse_blocks()) hd.ks /= 2;
     int nlin = nlin_for(hd.ks);
@@ -2582,6 +2663,10 @@ int launch_adam(const mopoe_model& mdl, int32_t present_mask, const mopoe_buffer
     return check_launch("k_adam");   // (the fragment-major weight copies included)
 }
 
+}  // namespace
+extern "C" int64_t mopoe_wgrad_scratch_floats(const mopoe_model* mdl, const mopoe_step* st);
+namespace {
+
 // `fuse_adam`: the weight-gradient launch applies the update itself (the one-rank step).
 // Otherwise the launches stop at the gradients -- with `adam` non-NULL the step's first
 // kernel still publishes its Adam records for the k_adam launch that follows an exchange.
@@ -2613,8 +2698,17 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
     //  does not advance the exchange's sequence number)
     if (comm && (int)grid.x > comm_flag_stride(comm))   // one arrival flag per exchanging workgroup
         return fail(MOPOE_ERR_ARG, "more weight-gradient blocks than the communicator has flags%s");
+    // (the split weight-gradient launches write `need` floats of scratch: the count depends on
+    //  the batch's modalities as well as on n, so it is checked here, before any launch)
+    const bool big = !comm && wgrad_big_step(ka.st) && buf->wgrad_scratch;
+    if (big) {
+        const int64_t need = mopoe_wgrad_scratch_floats(mdl, st);
+        if (buf->wgrad_scratch_floats < need)
+            return fail(MOPOE_ERR_ARG, "mopoe_buffers.wgrad_scratch holds fewer floats than "
+                                       "mopoe_wgrad_scratch_floats(model, step)%s");
+    }
     if (int rc = launch_forward_part(ka, adam, s)) return rc;
-    if (!comm && wgrad_big_step(ka.st) && buf->wgrad_scratch) {
+    if (big) {
         // a large batch: 64 x 64 tiles over slices of the batch rows, the parts added in order
         // by a second launch (+ Adam), then the launch's tail alone -- decoder-logvar blocks,
         // the step's scalars and bookkeeping (mopoe_wgrad_big.inc)
@@ -2884,6 +2978,10 @@ int mopoe_forward(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buff
     step_layout(ka.mdl, ka.st, ka.lds);
     latent_bind(ka.lds, ka.buf);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (buf->wgrad_scratch && cdiv(ka.st.n, ka.lds.rows) >= 8 * kFoldSlices &&
+        buf->wgrad_scratch_floats < (int64_t)kFoldSlices * ka.lds.part_stride)
+        return fail(MOPOE_ERR_ARG, "mopoe_buffers.wgrad_scratch holds fewer floats than "
+                                   "mopoe_wgrad_scratch_floats(model, step)%s");
     if (int rc = launch_forward_part(ka, nullptr, s)) return rc;
     {
         ProfScope ps(MOPOE_KERNEL_FINALIZE, s);
@@ -2992,7 +3090,7 @@ int mopoe_comm_create(int32_t rank, int32_t world, int32_t num_floats, int32_t t
     if (!out || !handle_out || world < 1 || world > MOPOE_MAX_RANKS || rank < 0 ||
         rank >= world || num_floats < 4 || num_floats % 4 != 0)
         return fail(MOPOE_ERR_ARG, "mopoe_comm_create: bad argument%s");
-    static_assert(sizeof(hipIpcMemHandle_t) == MOPOE_IPC_HANDLE_BYTES, "handle size");
+    static_assert(sizeof(hipIpcMemHandle_t) + 16 == MOPOE_IPC_HANDLE_BYTES, "handle size");
     mopoe_comm* c = new mopoe_comm();
     memset(c, 0, sizeof(*c));
     c->rank = rank;
@@ -3027,6 +3125,14 @@ int mopoe_comm_create(int32_t rank, int32_t world, int32_t num_floats, int32_t t
         return fail(MOPOE_ERR_HIP, "mopoe_comm_create: %s", hipGetErrorString(e));
     }
     memcpy(handle_out, &h, sizeof(h));
+    {   // ... followed by the device's UUID: ranks that share a device find out in mopoe_comm_connect
+        int dev = 0;
+        hipUUID id;
+        memset(&id, 0, sizeof(id));
+        static_assert(sizeof(id.bytes) == 16, "uuid size");
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetUuid(&id, dev) == hipSuccess) memcpy(c->uuid, id.bytes, 16);
+        memcpy(static_cast<char*>(handle_out) + sizeof(h), c->uuid, 16);
+    }
     c->mapped[rank] = c->window;
     *out = c;
     return 0;
@@ -3038,7 +3144,10 @@ int mopoe_comm_connect(mopoe_comm* c, const void* handles) {
     for (int r = 0; r < c->world; ++r) {
         if (r == c->rank) continue;
         hipIpcMemHandle_t h;
-        memcpy(&h, static_cast<const char*>(handles) + (size_t)r * sizeof(h), sizeof(h));
+        const char* rec = static_cast<const char*>(handles) + (size_t)r * MOPOE_IPC_HANDLE_BYTES;
+        memcpy(&h, rec, sizeof(h));
+        static const char kNoUuid[16] = {0};
+        if (memcmp(c->uuid, kNoUuid, 16) != 0 && memcmp(rec + sizeof(h), c->uuid, 16) == 0) c->shared_device = true;
         hipError_t e = hipIpcOpenMemHandle(&c->mapped[r], h, hipIpcMemLazyEnablePeerAccess);
         if (e != hipSuccess) {
             for (int q = 0; q < r; ++q)
@@ -3050,6 +3159,7 @@ int mopoe_comm_connect(mopoe_comm* c, const void* handles) {
         }
     }
     c->connected = true;
+    if (c->shared_device) g_shared_device_comms.fetch_add(1);
     return 0;
 }
 
@@ -3088,6 +3198,7 @@ int mopoe_comm_status(mopoe_comm* c, int32_t* timeouts) {
 
 int mopoe_comm_destroy(mopoe_comm* c) {
     if (!c) return 0;
+    if (c->connected && c->shared_device) g_shared_device_comms.fetch_sub(1);
     for (int r = 0; r < c->world; ++r)
         if (r != c->rank && c->mapped[r]) (void)hipIpcCloseMemHandle(c->mapped[r]);
     if (c->window) (void)hipFree(c->window);

@@ -254,8 +254,18 @@ class MoPoEEngine:
         return c[L.CTR_FIRST_INVALID], c[L.CTR_STEPS_BEGUN]
 
     def recover(self):
-        """Re-arm after an invalid step: clears the sticky word and the hand-off flags."""
+        """Re-arm after an invalid step: clears the sticky word and the hand-off flags, and
+        takes the step numbers back to the last APPLIED step -- the withheld steps
+        first .. begun never happened, so the caller's replay of their batches runs under
+        the same step numbers, and the device noise (Philox keyed by seed and step number)
+        and dropout masks of the replay are the ones an untroubled run draws: a retried run
+        ends bit for bit where its twin ends (tests/test_hip_dp_onecall.py)."""
         torch.cuda.synchronize(self.device)
+        c = self.counters[:4].tolist()
+        if c[L.CTR_INVALID] and c[L.CTR_FIRST_INVALID] > 0:
+            withheld = c[L.CTR_STEPS_BEGUN] - c[L.CTR_FIRST_INVALID] + 1
+            self.counters[L.CTR_STEPS_BEGUN] = c[L.CTR_FIRST_INVALID] - 1
+            self.counters[L.CTR_STEPS_DONE] = max(0, c[L.CTR_STEPS_DONE] - withheld)
         self.counters[L.CTR_INVALID] = 0
         self.counters[L.CTR_FIRST_INVALID] = 0
         for ws in self._ws.values():
@@ -341,6 +351,24 @@ class MoPoEEngine:
                 "mopoe_wfrag_refresh")
         self._wfrag_version = self.params._version
 
+    def _ensure_scratch(self, plan, ws):
+        """mopoe_buffers.wgrad_scratch for this step.  The count depends on the batch's
+        MODALITIES as well as on its rows (a workspace serves every batch of its shape:
+        clinical-only 719,360 floats, rois-only 3,013,120, both 3,668,480 at 4,096 rows), so
+        it is asked per plan (cached there) and the workspace's tensor grows to the largest
+        need seen; the library refuses a step whose need exceeds `wgrad_scratch_floats`.
+        `ws.wgrad_scratch = False` (tests) pins the one-launch form."""
+        if self.spec.general or ws.wgrad_scratch is False:
+            return
+        need = getattr(plan, "_scratch_need", None)
+        if need is None:
+            need = plan._scratch_need = int(
+                L.lib.mopoe_wgrad_scratch_floats(self.spec.c_model, plan.c_step))
+        have = ws.wgrad_scratch.numel() if torch.is_tensor(ws.wgrad_scratch) else 0
+        if need > have:
+            ws.wgrad_scratch = torch.empty(need, **ws._f)
+            ws._cbuf = None
+
     def _optim_buffers(self, b):
         if self._on_gpu and self.params._version != self._wfrag_version:
             self.refresh_wfrag()
@@ -378,6 +406,7 @@ class MoPoEEngine:
             b.stats = L.ptr(ws.stats)
             b.partials = L.ptr(ws.partials)
             b.wgrad_scratch = L.ptr(ws.wgrad_scratch) if torch.is_tensor(ws.wgrad_scratch) else None
+            b.wgrad_scratch_floats = ws.wgrad_scratch.numel() if torch.is_tensor(ws.wgrad_scratch) else 0
             self._optim_buffers(b)
             ws._cbuf, ws._cbuf_partials = b, ws.partials
         elif self._on_gpu and self.params._version != self._wfrag_version:
@@ -479,11 +508,7 @@ class MoPoEEngine:
         keep = self._bind_noise(plan, step, eps)
         self._calls += 1
         step.seed = (self.seed + 0x9E3779B97F4A7C15 * self._calls) & (2 ** 64 - 1)
-        if ws.wgrad_scratch is None and not self.spec.general:
-            # thousands of row groups: scratch for their pre-summed slabs (k_partials_fold)
-            need = L.lib.mopoe_wgrad_scratch_floats(self.spec.c_model, step)
-            ws.wgrad_scratch = torch.empty(need, **ws._f) if need else False
-            ws._cbuf = None
+        self._ensure_scratch(plan, ws)   # (thousands of row groups: their pre-summed slabs)
         buf = self._buffers(ws, x, row_index, plan=plan)
         if self.spec.general:       # (evaluation: the Dropout modules are the identity)
             self._bind_masks(plan, ws, None, False)
@@ -521,11 +546,7 @@ class MoPoEEngine:
         ws = self.workspace(n, slots, True, eb=eb)
         keep = self._bind_noise(plan, step, eps)
         step.seed = self.seed
-        if ws.wgrad_scratch is None and not self.spec.general:
-            # a large batch: scratch for the split weight-gradient launches (csrc/mopoe_wgrad_big.inc)
-            need = L.lib.mopoe_wgrad_scratch_floats(self.spec.c_model, step)
-            ws.wgrad_scratch = torch.empty(need, **ws._f) if need else False
-            ws._cbuf = None
+        self._ensure_scratch(plan, ws)   # (a large batch: the split weight-gradient launches)
         buf = self._buffers(ws, x, row_index, stats_host, plan=plan)
         adam = C.byref(self.adam) if apply_adam else None
         if self.spec.general:

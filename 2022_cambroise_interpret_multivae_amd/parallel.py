@@ -154,22 +154,30 @@ class DataParallelStep:
 class StepRetry:
     """The loop's policy for a step that could not be completed (reference
     run_epochs.py:180-182 applies a step or nothing): the kernels withhold the update from
-    the first invalid step on (sticky word, on every rank at the same step); this notices,
-    re-arms and runs the withheld batches ONCE more, and raises if that fails too.
+    the first invalid step on (sticky word); this notices, re-arms and runs the withheld
+    batches ONCE more, and raises if that fails too.
 
     `run(*args, **kw)` enqueues one training step.  One process: the pinned host mirror
     the kernels write is read after every step (no synchronisation).  Data-parallel
-    replicas must decide at the same step, so they look synchronously every `depth // 2`
-    steps and at `flush()` (the end of an epoch); `depth` batches are kept for the replay.
-    A replayed step draws fresh noise (the device generator is keyed by the step number)
-    and is logged again by the caller."""
+    replicas look synchronously every `depth // 2` steps and at `flush()` (the end of an
+    epoch), and the look itself is COLLECTIVE: every rank contributes (invalid, first
+    invalid step, steps begun) to an all-gather and all of them take the same branch and
+    replay the same batches -- also when only one rank saw the failure (a peer-window
+    time-out is seen by the rank that waited only; its peers used to walk on into the next
+    exchange while it re-synchronised: mismatched collectives, a hang).  `rank0_state`: the
+    recovery broadcasts rank 0's state (DataParallelStep.recover of the xgmi forms), so the
+    replay starts behind RANK 0's last applied step; otherwise (RCCL / all-reduce forms:
+    the control words withhold a step on every rank together) behind the earliest one.
+    `depth` batches are kept for the replay.  engine.recover() takes the step numbers back
+    to the last applied step, so a replayed step draws the noise of its first attempt."""
 
-    def __init__(self, engine, run, recover=None, depth=64, world=None):
+    def __init__(self, engine, run, recover=None, depth=64, world=None, rank0_state=False):
         self.engine = engine
         self.run = run
         self.recover = recover if recover is not None else engine.recover
         self.depth = int(depth)
         self.world = world_size() if world is None else world
+        self.rank0_state = bool(rank0_state)
         self.history = collections.deque(maxlen=self.depth)
         # (numpy view of the pinned host mirror the kernels write: a read costs no tensor op)
         self._mirror = engine.status_host.numpy()
@@ -181,17 +189,15 @@ class StepRetry:
         self.history.append((args, kw))
         self._since += 1
         if self.world == 1:
-            bad = self._mirror[1] != 0
-        else:
-            bad = self._since >= max(1, self.depth // 2) and self._look()
-        if bad:
-            out = self._redo() or out
+            if self._mirror[1] != 0:
+                out = self._redo(self.engine.invalid_since()) or out
+        elif self._since >= max(1, self.depth // 2):
+            out = self._redo(self._agreed()) or out
         return out
 
     def flush(self):
-        """Nothing invalid is left behind (synchronises)."""
-        if self._look():
-            self._redo()
+        """Nothing invalid is left behind (synchronises; collective over the replicas)."""
+        self._redo(self._agreed())
         self.history.clear()
 
     def end_epoch(self):
@@ -201,14 +207,39 @@ class StepRetry:
         if self.world > 1:
             self.flush()
         elif self._mirror[1] != 0:
-            self._redo()
+            self._redo(self.engine.invalid_since())
 
-    def _look(self):
+    def _agreed(self):
+        """(first step to run again, steps begun) -- the SAME pair on every rank -- or None
+        when no rank holds an invalid step.  Synchronises; collective when world > 1."""
         self._since = 0
-        return self.engine.invalid_since() is not None
-
-    def _redo(self):
         info = self.engine.invalid_since()
+        if self.world == 1 or not dist.is_initialized():
+            return info
+        begun = info[1] if info is not None else self.engine.step_count()
+        dev = self.engine.device if dist.get_backend() == "nccl" else "cpu"
+        mine = torch.tensor([1 if info is not None else 0, info[0] if info is not None else 0, begun],
+                            dtype=torch.int64, device=dev)
+        everyone = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(everyone, mine)
+        table = [t.tolist() for t in everyone]
+        if not any(row[0] for row in table):
+            return None
+        begun = max(row[2] for row in table)
+        if self.rank0_state:         # rank 0's state is what every rank continues from
+            first = table[0][1] if table[0][0] else table[0][2] + 1
+        else:
+            # the RCCL / all-reduce forms withhold a step on every rank together (the control
+            # words of the summed gradient buffer): ranks that disagree here are replicas that
+            # have come apart -- every rank sees the same table, so all of them raise
+            if not all(row[0] for row in table) or len({row[1] for row in table}) != 1:
+                raise L.MopoeError(
+                    "data-parallel replicas disagree on the steps that were withheld "
+                    "(invalid, first invalid step, steps begun per rank: %s)" % (table,))
+            first = table[0][1]
+        return first, begun
+
+    def _redo(self, info):
         if info is None:
             return None
         first, begun = info
@@ -217,13 +248,13 @@ class StepRetry:
             raise L.MopoeError(
                 "training steps %d..%d could not be completed and only the last %d batches "
                 "are kept for a retry" % (first, begun, len(self.history)))
-        replay = list(self.history)[-k:]
+        replay = list(self.history)[-k:] if k > 0 else []
         self.recover()
         self.retries += 1
         out = None
         for args, kw in replay:
             out = self.run(*args, **kw)
-        if self.engine.invalid_since() is not None:
+        if (self._agreed() if self.world > 1 else self.engine.invalid_since()) is not None:
             raise L.MopoeError(
                 "%d training step(s) could not be completed twice in a row (hand-off or "
                 "gradient-exchange time-out, or ranks with different modalities); the "

@@ -215,7 +215,8 @@ def _retry_guard(exp, model_idx, eng, dp_step):
         else:
             def run(inputs, row_index, weight):
                 return dp_step(inputs, row_index=row_index, loss_scale=weight, check=False)
-            guards[model_idx] = parallel.StepRetry(eng, run, recover=dp_step.recover)
+            guards[model_idx] = parallel.StepRetry(eng, run, recover=dp_step.recover,
+                                                   rank0_state=dp_step.exchange.startswith("xgmi"))
     return guards[model_idx]
 
 

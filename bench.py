@@ -48,27 +48,6 @@ import os
 import sys
 import time
 
-# The host waits for the GPU by polling instead of sleeping until an interrupt (ROCm's
-# HSA_ENABLE_INTERRUPT=0; it must be set before the runtime starts): a synchronisation then
-# costs ~5 us instead of 20-60.  A training run hardly ever synchronises, but the driver's
-# timed region is 20 steps = 0.6 ms between two of them: with interrupts its own brackets
-# were 3-5 us of every step it reported (35-39 us against 31.8-33.4 on the same box, the
-# 3,000-step figure 30.1 either way).  Reported as config.host_wait.
-os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
-
-import torch
-
-ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-
-import mopoe_amd as mm  # noqa: E402
-
-HIDDEN = 256
-# MI355X_MICROARCH.md: exact-f32 MFMA peak = vector peak; HBM3E spec
-PEAK_F32_MFMA_TFLOPS = 157.3
-PEAK_HBM_GBS = 8000.0
-POOL = int(os.environ.get("MOPOE_BENCH_POOL", "64"))   # resident batches
-
 CONFIGS = {
     # BASELINE.json configs[0] / [1] / [3]
     "C1": dict(names=["clinical", "rois"], dims=[7, 444], style=[3, 20], method="joint_elbo",
@@ -91,6 +70,128 @@ CONFIGS = {
                                     "bandwidth regime; not a BASELINE configuration)"),
 }
 LATENT = 20
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--settle", type=int, default=3000,
+                    help="untimed steps between the cold-start timing and the timing that "
+                         "produces `value` (reported as config.settle_steps)")
+    ap.add_argument("--no-log-copy", action="store_true",
+                    help="leave the per-step scalar log into pinned host memory out")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--quick", action="store_true",
+                    help="headline + roofline + cpu_baseline only (no other "
+                         "configs / regime / eager legs)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C1",
+                    help="the configuration the main loop runs (profiling: tools/"
+                         "profile_round.sh); the metric is quoted on C1 = configs[1]")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="rows per step over ALL ranks (each rank takes global / N; strong "
+                         "scaling).  BASELINE configs[4] as SURVEY 8d states it: --config C5 "
+                         "--global-batch 512 --gpus 8 = 64 rows per rank.  Default: the "
+                         "configuration's batch PER rank (weak scaling)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearse the multi-GPU step (rank spawn, process group, RCCL "
+                         "all-reduce, separate Adam kernel) even with one rank")
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="print the N child environments / command lines the launcher would "
+                         "start, as one JSON line, and start nothing")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------
+# The launcher: `python3 bench.py --gpus N` (no torchrun around it) starts its own N ranks.
+# It runs BEFORE torch, the package or anything else that could touch the GPU is imported: the
+# parent only spawns CHILD processes (never an exec, never a re-launch of a process that has
+# initialised HIP), waits for them, forwards rank 0's single JSON line and returns non-zero if
+# any rank did.  Under torch.distributed.run (WORLD_SIZE set) this is skipped: the process IS a rank.
+def rank_environments(n, port=None):
+    """The N child environments (only the variables the launcher sets)."""
+    if port is None:
+        import socket
+        with socket.socket() as s:        # a free port of the loopback interface
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [{"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+             "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+             # dmabuf IPC (the host driver supports nothing else: RCCL / peer windows need it)
+             "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+             "MOPOE_BENCH_SPAWNED": "1"} for r in range(n)]
+
+
+def launcher(args, argv):
+    import subprocess
+    n = args.gpus
+    if n < 1:
+        sys.exit("--gpus must be >= 1")
+    child_argv = [a for a in argv if a != "--launch-dry-run"]
+    envs = rank_environments(n, port=29400 if args.launch_dry_run else None)
+    cmd = [sys.executable, os.path.abspath(__file__)] + child_argv
+    if args.launch_dry_run:
+        print(json.dumps({"launch": "child processes (subprocess.Popen), one per GPU", "n_gpus": n,
+                          "cmd": cmd, "ranks": envs}), flush=True)
+        return 0
+    procs = []
+    for r, e in enumerate(envs):
+        # rank 0's stdout carries the JSON line; the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen(cmd, env=dict(os.environ, **e),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    line = b""
+    for raw in procs[0].stdout:           # (until rank 0 closes its stdout: it has ended)
+        if raw.strip():
+            line = raw
+    rcs = []
+    deadline = time.time() + 120.0        # the others end with rank 0 (last barrier) or are stopped
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()                       # (this exact child: never a pattern)
+            rcs.append(p.wait())
+    if any(rcs):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+        return next(rc for rc in rcs if rc) or 1
+    try:
+        json.loads(line)
+    except ValueError:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        return 1
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    return 0
+
+
+def wants_launcher(args):
+    """This process is the launcher (not a rank): nobody gave it a rank environment, and more
+    than one rank -- or the rehearsal of the rank-spawn path -- was asked for."""
+    return "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_dist or args.launch_dry_run)
+
+
+if __name__ == "__main__" and wants_launcher(parse_args()):
+    sys.exit(launcher(parse_args(), sys.argv[1:]))     # (before torch / the package are imported)
+
+# The package makes the host wait for the GPU by polling (HSA_ENABLE_INTERRUPT=0, set when it is
+# imported before the HIP runtime starts; MOPOE_HOST_WAIT=interrupt keeps ROCm's default): the
+# benchmark and a training run through run_epochs.train wait the same way.  Reported as
+# config.host_wait.
+import torch  # noqa: E402
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import mopoe_amd as mm  # noqa: E402
+
+HIDDEN = 256
+# MI355X_MICROARCH.md: exact-f32 MFMA peak = vector peak; HBM3E spec
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+POOL = int(os.environ.get("MOPOE_BENCH_POOL", "64"))   # resident batches
+
 
 
 def make_spec(c):
@@ -517,27 +618,7 @@ def check_in_backward(comm, spec, batch, device, world, dist):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--settle", type=int, default=3000,
-                    help="untimed steps between the cold-start timing and the timing that "
-                         "produces `value` (reported as config.settle_steps)")
-    ap.add_argument("--no-log-copy", action="store_true",
-                    help="leave the per-step scalar log into pinned host memory out")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--quick", action="store_true",
-                    help="headline + roofline + cpu_baseline only (no other "
-                         "configs / regime / eager legs)")
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="C1",
-                    help="the configuration the main loop runs (profiling: tools/"
-                         "profile_round.sh); the metric is quoted on C1 = configs[1]")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="rehearse the multi-GPU step (process group, all-reduce, separate "
-                         "Adam kernel) even with one rank")
-    args = ap.parse_args()
+    args = parse_args()
 
     # stdout carries ONE JSON line: whatever libraries print there while the run lasts (RCCL
     # greets with a version banner on stdout when it sets up a communicator) goes to stderr
@@ -549,12 +630,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with "
-                     "torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d inside a rank environment of WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     if world > 1 or args.force_dist:
+        # (no rank environment and one rank: the launcher above has started this process with
+        #  one; under torch.distributed.run the driver's environment is used as it is)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -562,7 +642,11 @@ def main():
     torch.cuda.set_device(device)
 
     c = CONFIGS[args.config]
-    BATCH = c["batch"]
+    if args.global_batch:
+        if args.global_batch % world or args.global_batch < world:
+            sys.exit("--global-batch %d does not split over %d ranks" % (args.global_batch, world))
+        c = dict(c, batch=args.global_batch // world)
+    BATCH = c["batch"]      # rows per rank and step
     spec = make_spec(c)
     eng = mm.MoPoEEngine(spec, device, seed=1234)
     eng.reset_parameters(torch.Generator().manual_seed(0))  # same on all ranks
@@ -716,11 +800,18 @@ def main():
         "value": round(BATCH * world * args.steps / dt, 1),
         "unit": "samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
+        "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": c["label"],
-                   "global_batch": BATCH * world,
+                   "global_batch": BATCH * world, "batch_per_rank": BATCH,
                    "parallelism": "dp%d" % world if dist is not None else "single",
+                   "launched_by": ("bench.py's own launcher (child processes)"
+                                   if os.environ.get("MOPOE_BENCH_SPAWNED") else
+                                   "torch.distributed.run" if "WORLD_SIZE" in os.environ else
+                                   "single process"),
+                   "exchange_form": exchange,
+                   "rccl": ({"world": rccl.world, "rank": rccl.rank} if rccl is not None else None),
                    "exchange": {"none": "none (single GPU: Adam fused into the "
                                         "weight-gradient launch)",
                                 "xgmi": ("xGMI peer windows inside the weight-gradient launch: "

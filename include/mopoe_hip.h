@@ -28,13 +28,13 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 10
+#define MOPOE_ABI_VERSION 11
 #define MOPOE_MAX_MODS 5      /* modalities                                   */
 #define MOPOE_MAX_SUBSETS 31  /* 2^MAX_MODS - 1 non-empty subsets             */
 #define MOPOE_MAX_JOBS 10     /* decoder passes: 1 joint + 1 unimodal per mod */
 #define MOPOE_HIDDEN 256      /* networks/networks.py:14,50 (hard-coded)      */
 #define MOPOE_MAX_RANKS 8     /* GPUs of one node (xGMI full mesh)            */
-#define MOPOE_IPC_HANDLE_BYTES 64
+#define MOPOE_IPC_HANDLE_BYTES 80 /* hipIpcMemHandle_t (64) + the device's UUID (16): ABI 11 */
 #define MOPOE_RCCL_ID_BYTES 128 /* ncclUniqueId                                  */
 #define MOPOE_ROWS 16         /* batch rows per MFMA tile; a row group has <= 16 */
 #define MOPOE_MAX_LAYERS 4    /* hidden layers of an encoder / a decoder (general topology) */
@@ -281,6 +281,11 @@ typedef struct mopoe_buffers {
                                             (mopoe_forward: those slabs alone);
                                             NULL, or a step whose count is 0: the one-launch
                                             form                                          */
+    int64_t wgrad_scratch_floats;        /* floats `wgrad_scratch` holds (ABI 11).  The count a
+                                            step needs depends on n AND on which modalities
+                                            the batch holds: a call whose step needs more than
+                                            this returns MOPOE_ERR_ARG and launches nothing
+                                            (it used to write past the buffer)            */
 } mopoe_buffers;
 
 typedef struct mopoe_adam {
@@ -376,10 +381,16 @@ int mopoe_adam_step(const mopoe_model* model, int32_t present_mask,
  * buffers + arrival flags), exported to the other ranks' processes with
  * hipIpcGetMemHandle; this is the one object of the library that allocates.
  *
- *   mopoe_comm_create   allocates the window and returns its 64-byte IPC handle;
- *                       the caller exchanges the handles out of band (e.g.
+ *   mopoe_comm_create   allocates the window and returns MOPOE_IPC_HANDLE_BYTES: its
+ *                       64-byte IPC handle followed by the 16-byte UUID of the rank's
+ *                       device; the caller exchanges the records out of band (e.g.
  *                       torch.distributed.all_gather_object) ...
- *   mopoe_comm_connect  ... and passes all `world` of them (rank order).
+ *   mopoe_comm_connect  ... and passes all `world` of them (rank order).  A peer whose
+ *                       UUID is this rank's own shares the device (ranks time-slicing one
+ *                       GPU: the one-GPU rehearsal of the node): other processes' grids on
+ *                       the same compute units break the residency the fused launch's
+ *                       in-kernel hand-off needs, so while such a communicator exists every
+ *                       step of the process runs in separate launches (same bits).
  *   mopoe_comm_allreduce_adam
  *                       replaces `all_reduce(grads); mopoe_adam_step(1/world)`:
  *                       one launch pushes buf->grads to every peer over its xGMI
@@ -533,6 +544,9 @@ int mopoe_rccl_create(int32_t rank, int32_t world, const void* id, mopoe_rccl** 
 int mopoe_rccl_train_step(mopoe_rccl* comm, const mopoe_model* model, const mopoe_step* step,
                           const mopoe_buffers* buf, const mopoe_adam* adam, void* stream);
 int mopoe_rccl_allreduce(mopoe_rccl* comm, float* data, int64_t count, void* stream);
+/* what RCCL itself says about the communicator (ncclCommUserRank / ncclCommCount), not what
+ * the caller passed to mopoe_rccl_create: bench.py prints it next to n_gpus (ABI 11) */
+int mopoe_rccl_info(mopoe_rccl* comm, int32_t* rank, int32_t* world);
 int mopoe_rccl_destroy(mopoe_rccl* comm);
 
 /* ---------------------------------------------------------------------------

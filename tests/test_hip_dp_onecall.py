@@ -216,8 +216,9 @@ class _Scripted:
     sees the eps a twin's first attempt saw) and a hand-off time-out forced on chosen
     calls of train_step."""
 
-    def __init__(self, eng, cfg, fail_calls=()):
+    def __init__(self, eng, cfg, fail_calls=(), device_noise=False):
         self._eng, self._cfg, self._fail, self.calls = eng, cfg, set(fail_calls), 0
+        self._device_noise = device_noise    # no eps injected: the kernels' own Philox draws
 
     def __getattr__(self, name):
         return getattr(self._eng, name)
@@ -227,7 +228,7 @@ class _Scripted:
         first = next(iter(ri))
         rows = ri[first]
         key = int(rows.sum().item()) * 31 + len(rows) + 7 * len(inputs)
-        eps = _eps(self._cfg, len(rows), key, list(inputs))
+        eps = None if self._device_noise else _eps(self._cfg, len(rows), key, list(inputs))
         fail = self.calls in self._fail
         self.calls += 1
         if fail:
@@ -274,3 +275,28 @@ def test_the_loop_retries_a_step_that_could_not_be_completed():
     np.random.seed(11)
     with pytest.raises(L.MopoeError, match="twice in a row"):
         run_epochs.train(0, 0, _exp(always, cohort), None)
+
+
+def test_a_retried_step_draws_the_noise_of_its_first_attempt():
+    """The device noise is keyed by (seed, step number); engine.recover() takes the step
+    numbers back to the last applied step, so the replay of a withheld batch runs under its
+    own number again: with the kernels' OWN noise (nothing injected) an epoch with two
+    retried steps ends bit for bit where an untroubled twin of the same seed ends."""
+    cfg = mo.Config(**CFG)
+    ds = _cohort()
+    cohort = dataset.ResidentCohort(ds, "cuda")
+    _, eng = make_engine(cfg)
+    _, twin = make_engine(cfg)
+    assert eng.seed == twin.seed
+    failing = _Scripted(eng, cfg, fail_calls=[1, 4], device_noise=True)
+    clean = _Scripted(twin, cfg, device_noise=True)
+    for proxy in (failing, clean):
+        np.random.seed(11)
+        run_epochs.train(0, 0, _exp(proxy, cohort), None)
+    torch.cuda.synchronize()
+    steps = len(dataset.MissingModalitySampler(ds, 256))
+    assert clean.calls == steps and failing.calls >= steps + 2
+    eng.check_valid(sync=True)
+    assert eng.step_count() == twin.step_count() == steps      # withheld attempts do not count
+    assert torch.equal(eng.params, twin.params)
+    assert torch.equal(eng.exp_avg, twin.exp_avg) and torch.equal(eng.exp_avg_sq, twin.exp_avg_sq)

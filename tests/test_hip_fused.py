@@ -136,3 +136,52 @@ def test_specialised_forms_are_bit_identical_to_the_generic_one(shape, monkeypat
     for a, b, d in zip(special, generic, plain):
         assert torch.equal(a, b)
         assert torch.equal(a, d)
+
+
+def _forms_of(steps, n, method):
+    """Launch counts per kernel over `steps` training steps (the library's event log)."""
+    L = mm._lib
+    spec = mm.ModelSpec(["clinical", "rois"], [7, 444], [3, 20], method=method)
+    eng = mm.MoPoEEngine(spec, "cuda", seed=5)
+    eng.reset_parameters(torch.Generator().manual_seed(0))
+    g = torch.Generator().manual_seed(1)
+    x = {"clinical": torch.randn(n, 7, generator=g).cuda(), "rois": torch.randn(n, 444, generator=g).cuda()}
+    L.profile_enable(True)
+    try:
+        for _ in range(steps):
+            eng.train_step(x)
+        torch.cuda.synchronize()
+        prof = L.profile_read()
+    finally:
+        L.profile_enable(False)
+    eng.check_valid(sync=True)
+    return {k: v[0] for k, v in prof.items()}
+
+
+def test_oversubscribed_launch_is_held_to_the_device(monkeypatch):
+    """The launch of more workgroups than compute units (row groups spinning on producers of the
+    same grid) is only taken while every producer is resident first -- counted on the device the
+    call runs on (its CU count x the runtime's occupancy for the kernel; MOPOE_FUSE_BLOCKS stands
+    in for a smaller device here), not on the constant 256.  Method poe, 768 rows, four K parts =
+    240 producers + 192 row groups: on 256 CUs one launch; told that 200 workgroups fit, the
+    encoder layer must run as a launch of its own in front of the row groups -- the form
+    MOPOE_QUAD_OVERSUB=0 selects, bit for bit."""
+    monkeypatch.delenv("MOPOE_NO_FUSE", raising=False)
+    monkeypatch.delenv("MOPOE_QUAD", raising=False)
+    monkeypatch.setenv("MOPOE_QUAD_OVERSUB", "4")
+    whole = _forms_of(4, 768, "poe")
+    assert whole["k_fused"] == 4 and whole["k_linear"] == 0        # one launch, producers inside
+    monkeypatch.setenv("MOPOE_FUSE_BLOCKS", "200")
+    held = _forms_of(4, 768, "poe")
+    assert held["k_fused"] == 4 and held["k_linear"] == 4          # the fallback form ran
+    guarded = _train(300, 5, 768, "poe")
+    monkeypatch.delenv("MOPOE_FUSE_BLOCKS")
+    monkeypatch.setenv("MOPOE_QUAD_OVERSUB", "0")
+    split = _train(300, 5, 768, "poe")
+    for a, b in zip(guarded, split):
+        assert torch.equal(a, b)
+    # fewer "CUs" than row groups: no four-row form at all, and nothing fused that does not fit
+    monkeypatch.setenv("MOPOE_FUSE_BLOCKS", "100")
+    monkeypatch.setenv("MOPOE_QUAD_OVERSUB", "4")
+    small = _forms_of(2, 768, "poe")
+    assert small["k_fused"] == 0 and small["k_latent"] == 2 and small["k_linear"] == 2

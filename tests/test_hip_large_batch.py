@@ -116,3 +116,61 @@ def test_split_form_agrees_with_the_one_launch_form_and_keeps_the_weight_copies(
     for k, g in grads.items():
         rep.close_scaled("grad/" + k, a.grad_views[k], g, TOL["grad"])
     rep.finish()
+
+
+def test_scratch_follows_the_batch_modalities():
+    """One workspace serves every batch of its shape, but the scratch of the split weight-
+    gradient launches depends on WHICH modalities the batch holds (4,096 rows: clinical only
+    719,360 floats, rois only 3,013,120, both 3,668,480): a cohort epoch of missing-modality
+    batches used to size it from the first batch and let later ones write past it.  The
+    engine now asks per plan and grows the tensor; every step against the oracle."""
+    cfg = mo.Config(**C1)
+    spec, eng = make_engine(cfg)
+    n = 4096
+    params = mo.init_params(cfg, 0)
+    state = mo.adam_init(params)
+    full = mo.make_inputs(cfg.names, cfg.input_dim, n, seed=21)
+    seen = []
+    for step, names in enumerate((["clinical"], ["rois"], ["clinical", "rois"], ["clinical"])):
+        x = OrderedDict((k, full[k]) for k in names)
+        noise = mo.Noise(generator=mo.noise_rng(30 + step))
+        out, grads = mo.train_step(params, cfg, x, noise, state)
+        plan, ws = eng.train_step(x, eps=noise.tape)
+        torch.cuda.synchronize()
+        eng.check_valid(sync=True)
+        need = L.lib.mopoe_wgrad_scratch_floats(spec.c_model, plan.c_step)
+        assert need > 0 and ws.wgrad_scratch.numel() >= need
+        seen.append(need)
+        rep = Report("scratch per plan: %s" % "+".join(names))
+        compare_forward(rep, spec, eng, plan, ws, out, check_scale=False)
+        for k, g in grads.items():
+            rep.close_scaled("grad/" + k, eng.grad_views[k], g, TOL["grad"])
+        rep.finish()
+    assert seen[0] < seen[1] < seen[2] and seen[3] == seen[0]    # (the needs really differ)
+    for k, v in params.items():
+        torch.testing.assert_close(eng.named_params()[k].cpu(), v, rtol=2e-4, atol=2e-6)
+
+
+def test_library_refuses_an_undersized_scratch():
+    """mopoe_buffers.wgrad_scratch_floats (ABI 11): a step that needs more is an argument
+    error before anything is launched, not a write past the buffer."""
+    cfg = mo.Config(**C1)
+    spec, eng = make_engine(cfg)
+    n = 4096
+    x = {k: v.cuda() for k, v in mo.make_inputs(cfg.names, cfg.input_dim, n, seed=22).items()}
+    plan = spec.plan(list(x), n, backward=True)
+    ws = eng.workspace(n, 1, True)
+    eng._ensure_scratch(plan, ws)
+    buf = eng._buffers(ws, x, None, plan=plan)
+    need = L.lib.mopoe_wgrad_scratch_floats(spec.c_model, plan.c_step)
+    assert buf.wgrad_scratch_floats == need
+    before = eng.params.clone()
+    buf.wgrad_scratch_floats = need - 1
+    rc = L.lib.mopoe_train_step(spec.c_model, plan.c_step, buf, None, L.stream_ptr())
+    assert rc == -1 and b"wgrad_scratch" in L.lib.mopoe_last_error()
+    torch.cuda.synchronize()
+    assert eng.step_count() == 0 and torch.equal(eng.params, before)    # (nothing was launched)
+    buf.wgrad_scratch_floats = need
+    L.check(L.lib.mopoe_train_step(spec.c_model, plan.c_step, buf, None, L.stream_ptr()), "train")
+    torch.cuda.synchronize()
+    eng.check_valid(sync=True)

@@ -25,10 +25,11 @@ def test_exchange_and_fused_adam_between_processes(world):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0",
                    # W processes share this box's one GPU: the fused launch assumes its
-                   # whole grid is resident, which other processes' grids on the same
-                   # CUs break -- the ranks run the three-launch form here (same bits,
-                   # tests/test_hip_fused.py); on the node every rank has its own GPU
-                   MOPOE_NO_FUSE="1",
+                   # whole grid is resident, which other processes' grids on the same CUs
+                   # break.  The library finds that out by itself (mopoe_comm_connect compares
+                   # the device UUIDs that travel with the IPC handles) and runs the steps of
+                   # this communicator in separate launches -- same bits, tests/test_hip_fused.py;
+                   # on the node every rank has its own GPU.  (No MOPOE_NO_FUSE here any more.)
                    # the exchange INSIDE the weight-gradient launch is rehearsed with two
                    # ranks only: its waiting workgroups hold most of a CU's registers,
                    # and with three other ranks' launches waiting on the same GPU a

@@ -243,3 +243,91 @@ def test_shares_of_the_rank_aware_sampler():
             assert list(got) == list(b)                      # a partition, in order
             assert abs(sum(parts[r][1][k] for r in range(world)) - world) < 1e-9
             assert all(len(parts[r][0][k]) >= 1 for r in range(world))
+
+
+# ------------------------------------------------------------ StepRetry decides collectively
+class _ScriptedEngine:
+    """The part of the engine StepRetry talks to, with a failure scripted per rank: the
+    step numbered `fail_at` could not be completed on the ranks in `fail_ranks` (first
+    attempt only); steps behind it are withheld there until recover()."""
+
+    def __init__(self, rank, fail_at, fail_ranks):
+        self.device = torch.device("cpu")
+        self.status_host = torch.zeros(4, dtype=torch.int32)
+        self.begun, self.first, self.recovered, self.log = 0, 0, 0, []
+        self._fail = fail_at if rank in fail_ranks else None
+
+    def run(self, tag):
+        self.begun += 1
+        if self._fail is not None and self.begun == self._fail and not self.recovered:
+            self.first = self.begun
+        self.log.append((tag, self.begun, "withheld" if self.first else "applied"))
+
+    def invalid_since(self):
+        return (self.first, self.begun) if self.first else None
+
+    def step_count(self):
+        return self.begun
+
+    def recover(self):
+        if self.first:      # (engine.recover: step numbers back to the last applied step)
+            self.begun = self.first - 1
+        self.first = 0
+        self.recovered += 1
+
+
+def _retry_worker(rank, world, port, fail_ranks, rank0_state, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = _ScriptedEngine(rank, fail_at=3, fail_ranks=fail_ranks)
+    recover = eng.recover
+    if rank0_state:         # DataParallelStep.recover of the xgmi forms: rank 0's state everywhere
+        def recover():
+            eng.recover()
+            t = torch.tensor([eng.begun])
+            dist.broadcast(t, 0)
+            eng.begun = int(t.item())
+    guard = parallel.StepRetry(eng, eng.run, recover=recover, depth=8, rank0_state=rank0_state)
+    err = ""
+    try:
+        for tag in "abcde":     # depth // 2 = 4: the ranks look after step 4 and at the flush
+            guard.step(tag)
+        guard.flush()
+    except L.MopoeError as e:
+        err = str(e)
+    ret[rank] = (list(eng.log), eng.recovered, guard.retries, eng.begun, err)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_ranks,rank0_state", [((0, 1), False), ((1,), False), ((1,), True),
+                                                    ((0,), True)])
+def test_step_retry_decides_over_all_ranks(fail_ranks, rank0_state):
+    """A failure that ONE rank saw (a peer-window time-out) used to send that rank alone
+    into recover() -- c10d broadcasts its peers never joined.  The look is an all-gather now:
+    every rank re-arms and replays the same batches."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_retry_worker, args=(2, port, fail_ranks, rank0_state, ret), nprocs=2, join=True)
+    (log0, rec0, tries0, begun0, err0), (log1, rec1, tries1, begun1, err1) = ret[0], ret[1]
+    if not rank0_state and len(fail_ranks) == 1:
+        # the all-reduce forms cannot withhold a step on one rank alone: replicas that say so
+        # have come apart, and BOTH ranks raise (nobody is left waiting in a collective)
+        assert "disagree" in err0 and "disagree" in err1
+        assert rec0 == rec1 == 0
+        return
+    assert not err0 and not err1
+    assert rec0 == rec1 == 1 and tries0 == tries1 == 1      # both ranks re-armed, once
+    assert [t for t, _, _ in log0] == [t for t, _, _ in log1]   # ... and ran the same batches
+    assert begun0 == begun1 == 5                              # five batches, five applied steps
+    tags = [t for t, _, _ in log0]
+    if rank0_state and 0 not in fail_ranks:
+        # rank 0 applied everything: its state is broadcast, nothing is run again
+        assert tags == list("abcde")
+    else:
+        # steps 3 and 4 were withheld (somewhere): their batches run again, as steps 3 and 4
+        assert tags == list("abcd") + list("cd") + ["e"]
+        assert [n for _, n, _ in log0][4:6] == [3, 4]
