@@ -264,6 +264,39 @@ def pmc_traffic(kernel, cfg="C1"):
         return None
 
 
+def pmc_insts(kernel, cfg="C1"):
+    """The SQ instruction-issue counters of `kernel` from the newest committed pass
+    (profiles/*_pmc_insts_<config>.json, tools/pmc_insts.py: rocprofv3 --pmc over `bench.py
+    --config <config>`), reduced to the fractions the roofline object carries; None without one.
+      mfma_busy_frac   SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES): the share of the
+                       SIMD-cycles of the CUs that held a workgroup, while they held one, in which
+                       the MFMA pipe was busy (x share of CUs busy = chip-level utilisation)
+      wave cycles      parked on s_waitcnt / barrier (wait_any), issue-stalled (wait_inst_any),
+                       issuing (active_inst_any; of which vector ALU: active_inst_valu)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_insts_%s.json" % cfg)))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            ks = json.load(f)["kernels"]
+        key = next((k for k in ks if k == kernel or k.startswith(kernel + "<")), None)
+        d, p = ks[key]["derived"], ks[key]["per_launch"]
+        out = {"source": os.path.basename(files[-1]), "kernel": key,
+               "mfma_busy_frac": d.get("mfma_busy_frac_of_busy_cu_simd_cycles"),
+               "mfma_busy_frac_of_chip": d.get("mfma_busy_frac_of_chip"),
+               "wait_any_frac": d.get("wait_any_frac_of_wave_cycles"),
+               "wait_inst_any_frac": d.get("wait_inst_any_frac_of_wave_cycles"),
+               "active_inst_any_frac": d.get("active_inst_any_frac_of_wave_cycles"),
+               "active_inst_valu_frac": d.get("active_inst_valu_frac_of_wave_cycles"),
+               "active_inst_scalar_frac": d.get("active_inst_scalar_frac_of_wave_cycles"),
+               "insts_per_wave": {k[:-9]: v for k, v in d.items() if k.endswith("_per_wave") and k.startswith("insts_")},
+               "waves": p.get("SQ_WAVES")}
+        return out
+    except (KeyError, ValueError, OSError, TypeError):
+        return None
+
+
 def make_pool(c, device, count=POOL, seed=1234):
     g = torch.Generator().manual_seed(seed)
     return [{n: torch.randn(c["batch"], d, generator=g).to(device)
@@ -304,7 +337,10 @@ def roofline_of(spec, n, prof, dt_per_step, fused_adam, world, traffic="C1"):
         achieved = km["bytes"] / avg_s / 1e9
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS,
                 "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 5)}
+    insts = pmc_insts(name, traffic) if traffic else None
     roof.update({"traffic": pmc_traffic(name, traffic) if traffic else None, "kernel": name,
+                 "mfma_busy_frac": insts["mfma_busy_frac"] if insts else None,
+                 "issue_counters": insts,
                  "avg_us": round(avg_s * 1e6, 3),
                  "share_of_device_time": round(ms / total_ms, 3),
                  "kernels_avg_us": {k: round(v, 3) for k, v in avg_us.items()},

@@ -118,37 +118,56 @@ def test_split_form_agrees_with_the_one_launch_form_and_keeps_the_weight_copies(
     rep.finish()
 
 
+def _near_kink(cfg, params, x, eps=3e-6):
+    """Hidden units whose pre-activation is within `eps` of ReLU's kink anywhere in the batch
+    (two float32 summation orders may disagree on their mask: see the first test)."""
+    out = {}
+    for name in x:
+        e = "encoders.%s.shared_encoder.0." % name
+        pre = x[name].double() @ params[e + "weight"].double().t() + params[e + "bias"].double()
+        out[name] = (pre.abs() < eps).any(0)
+    return out
+
+
 def test_scratch_follows_the_batch_modalities():
     """One workspace serves every batch of its shape, but the scratch of the split weight-
     gradient launches depends on WHICH modalities the batch holds (4,096 rows: clinical only
     719,360 floats, rois only 3,013,120, both 3,668,480): a cohort epoch of missing-modality
     batches used to size it from the first batch and let later ones write past it.  The
-    engine now asks per plan and grows the tensor; every step against the oracle."""
+    engine now asks per plan and grows the tensor; every step's gradients against the oracle
+    (same parameters every step: the steps are not applied)."""
     cfg = mo.Config(**C1)
     spec, eng = make_engine(cfg)
     n = 4096
     params = mo.init_params(cfg, 0)
-    state = mo.adam_init(params)
     full = mo.make_inputs(cfg.names, cfg.input_dim, n, seed=21)
     seen = []
     for step, names in enumerate((["clinical"], ["rois"], ["clinical", "rois"], ["clinical"])):
         x = OrderedDict((k, full[k]) for k in names)
         noise = mo.Noise(generator=mo.noise_rng(30 + step))
-        out, grads = mo.train_step(params, cfg, x, noise, state)
-        plan, ws = eng.train_step(x, eps=noise.tape)
+        out, grads = mo.loss_and_grads(params, cfg, x, noise)
+        guard = torch.full((1 << 20,), 7.0, device="cuda")     # (allocated right behind: a write
+        plan, ws = eng.train_step(x, eps=noise.tape, apply_adam=False)   # past the scratch lands here)
         torch.cuda.synchronize()
         eng.check_valid(sync=True)
         need = L.lib.mopoe_wgrad_scratch_floats(spec.c_model, plan.c_step)
         assert need > 0 and ws.wgrad_scratch.numel() >= need
+        assert bool((guard == 7.0).all())
         seen.append(need)
+        kink = _near_kink(cfg, params, x)
+        assert sum(int(v.sum()) for v in kink.values()) <= 32
         rep = Report("scratch per plan: %s" % "+".join(names))
         compare_forward(rep, spec, eng, plan, ws, out, check_scale=False)
         for k, g in grads.items():
-            rep.close_scaled("grad/" + k, eng.grad_views[k], g, TOL["grad"])
+            m = k.split(".")[1]
+            got = eng.grad_views[k].cpu()
+            if ".shared_encoder.0." in k:           # rows of W1 / b1: the unit itself
+                got, g = got[~kink[m]], g[~kink[m]]
+            elif k.startswith("encoders.") and k.endswith(".weight"):   # head weights: its column
+                got, g = got[:, ~kink[m]], g[:, ~kink[m]]
+            rep.close_scaled("grad/" + k, got, g, TOL["grad"])
         rep.finish()
     assert seen[0] < seen[1] < seen[2] and seen[3] == seen[0]    # (the needs really differ)
-    for k, v in params.items():
-        torch.testing.assert_close(eng.named_params()[k].cpu(), v, rtol=2e-4, atol=2e-6)
 
 
 def test_library_refuses_an_undersized_scratch():
