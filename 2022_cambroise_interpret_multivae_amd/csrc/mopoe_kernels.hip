@@ -143,6 +143,7 @@ struct LinArgs {
     int32_t spins;         // fused launch: polls of a row group before it gives up
     int32_t knock;         // (diagnostic build -DMOPOE_KNOCK: phases to leave out)
     int32_t bf16;          // mopoe_step.gemm_operands == MOPOE_OPERANDS_BF16 (k_linear_big only)
+    int32_t xcd_order;     // k_linear_big: XCD-aware tile order (MOPOE_LIN_XCD, default 1)
     int32_t sig_n, sig_stride, sig_groups;   // fused launch: row groups per 16-row tile, words
                                              // between their flags, row groups in all
     mopoe_adam adam;
@@ -532,7 +533,21 @@ __global__ __launch_bounds__(ROWS * 4, MOPOE_LB_MINW) void k_linear_big(const Li
         step_begin(a.counters, a.num_mods, a.publish ? &a.adam : nullptr);
     }
     const LinGroup& g = a.g[blockIdx.z];
-    const int j0 = blockIdx.x * kBigCols, n0 = blockIdx.y * ROWS;
+    // Workgroups reach the XCDs round robin in launch order (column tile fastest): the four
+    // column tiles of a row tile would sit on four XCDs and each of their L2s would fetch the
+    // same x rows (measured at 65,536 rows: 2.6 x the algorithmic bytes).  Tile p = (L % 8) *
+    // (tiles / 8) + L / 8 of launch index L gives an XCD a run of consecutive tiles -- all
+    // column tiles of its row tiles -- so an x tile is fetched into ONE L2.  (Speed only.)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.xcd_order) {
+        const int gx = gridDim.x, per = (gx * (int)gridDim.y) >> 3, l = bx + gx * by;
+        if (l < 8 * per) {
+            const int p = (l & 7) * per + (l >> 3);
+            by = p / gx;
+            bx = p - by * gx;
+        }
+    }
+    const int j0 = bx * kBigCols, n0 = by * ROWS;
     if (j0 >= g.ncols) return;
     const int K = g.K;
     if (tid < ROWS) {
@@ -1090,7 +1105,11 @@ struct WArgs {
 // TI = 1: a 16-row tile -- one A fragment, G[r][i0 + c] -> output rows i = i0 + 4q' + reg.
 // FOLD: also add up the column sums of G (WJob::fold) -- an instantiation of its own: two adds per
 // MFMA step cost the jobs that do not need them 5 % at 65,536 rows.
-template <bool GATHER, int STEPS, int TI, bool FOLD>  // STEPS MFMA steps (4 batch rows each) per round: 16 or 8
+// PIPE: a wave with more than one round (1,024 rows over 8 waves: two) requests round k + 1
+// before it issues the MFMAs of round k, so one load round trip (~1.5-2 us under the launch's
+// own traffic) instead of one per round sits in front of the MFMAs.  Every round's requests
+// are guarded offsets, so the round behind the last one is requested too and reads nothing.
+template <bool GATHER, int STEPS, int TI, bool FOLD, bool PIPE = false>  // STEPS MFMA steps (4 batch rows each) per round: 16 or 8
 DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int ldg_, int ldx,
                     int gcols, int xcols, int i0, int j0, int rbeg, int rend, int lane,
                     f32x4 (&acc)[2][2], float (&bsum)[2]) {
@@ -1101,14 +1120,13 @@ DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int
     const uint32_t am0 = ci < gcols ? 0xFFFFFFFFu : 0u, am1 = ((TI == 2) & (ci + 1 < gcols)) ? 0xFFFFFFFFu : 0u;
     const uint32_t bm0 = cj < xcols ? 0xFFFFFFFFu : 0u, bm1 = cj + 1 < xcols ? 0xFFFFFFFFu : 0u;
     const float one0 = cj == xcols ? 1.f : 0.f, one1 = cj + 1 == xcols ? 1.f : 0.f;
-    for (int rb = rbeg; rb < rend; rb += 4 * STEPS) {
+    auto request = [&](int rb, f32x2 (&av)[STEPS], f32x2 (&bv)[STEPS]) {
         int xrow[STEPS];
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int r = rb + 4 * s + q;
             xrow[s] = GATHER ? xrows[min(r, rend - 1)] : r;
         }
-        f32x2 av[STEPS], bv[STEPS];
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int r = rb + 4 * s + q;
@@ -1123,6 +1141,8 @@ DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int
             bv[s] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
                         xr, guard((uint32_t)(xrow[s] * ldx + cj) * 4u, rv & (cj < xcols)), 0, 0));
         }
+    };
+    auto multiply = [&](int rb, const f32x2 (&av)[STEPS], const f32x2 (&bv)[STEPS]) {
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const bool rv = rb + 4 * s + q < rend;
@@ -1145,9 +1165,35 @@ DEV void wgrad_rows(rsrc_t gr, rsrc_t xr, const int32_t* __restrict__ xrows, int
                 acc[1][1] = mfma_16x16x4(fa1, fb1, acc[1][1]);
             }
         }
+    };
+    if constexpr (PIPE) {
+        f32x2 a0[STEPS], b0[STEPS], a1[STEPS], b1[STEPS];
+        request(rbeg, a0, b0);
+        // two half rounds per trip, each buffer refilled right after its values went into the
+        // MFMAs (no register copies: a copy out of a load's destination waits for the load).  An
+        // odd count of half rounds multiplies one buffer of zeros at the end (guarded requests
+        // past the last row return zeros; adding 0 x 0 leaves the sums as they are).
+        for (int rb = rbeg; rb < rend; rb += 8 * STEPS) {
+            request(rb + 4 * STEPS, a1, b1);
+            multiply(rb, a0, b0);
+            request(rb + 8 * STEPS, a0, b0);
+            multiply(rb + 4 * STEPS, a1, b1);
+        }
+    } else {
+        for (int rb = rbeg; rb < rend; rb += 4 * STEPS) {
+            f32x2 av[STEPS], bv[STEPS];
+            request(rb, av, bv);
+            multiply(rb, av, bv);
+        }
     }
 }
 
+#ifndef MOPOE_WGRAD_PIPE
+#define MOPOE_WGRAD_PIPE 2
+#endif
+#ifndef MOPOE_WGRAD_W16
+#define MOPOE_WGRAD_W16 1
+#endif
 constexpr int kWgLd = 36;  // leading dim of a 32x32 partial block in LDS
 
 // kWgWaves waves split the batch rows of a block: 8 for large batches (twice as fast at
@@ -1176,6 +1222,10 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
     uint32_t karg_sink = 0;
     for (int line = wave; line < (int)(sizeof(WArgs) / 64); line += kWgWaves)
         karg_sink |= ((const uint32_t*)(kargs + sizeof(KArgs)))[line * 16];
+    // (An XCD-aware order of the GEMM tiles -- an XCD's blocks a compact patch of a job's output,
+    //  its operand panels in ONE L2 -- was built and measured in round 4: no faster here, and the
+    //  fused launch behind it 1.3 us slower at 1,024 rows (the updated weights then sit in other
+    //  XCDs' L2s than the ones its producers run on): profiles/r04_c_ab_k_wgrad_variants.txt.)
     const int b = blockIdx.x;
     const bool fuse = w.fuse_adam != 0;
     const bool stamp_blk = b == 20 && tid == 0;  // a W1 block of the large modality
@@ -1237,40 +1287,55 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
         // rounds of 64 batch rows (32 loads in flight), or of 32 when a wave's share is
         // no more than that (the padded steps of a long round would still issue MFMAs)
         const bool half = rq <= 32;
+        // More than one round per wave: the pipelined instantiations -- half rounds of 8 steps in
+        // two buffers (the 64 registers of one full round, 32 loads in flight as before; full
+        // rounds in two buffers spilled: 256 VGPRs + 80 bytes of scratch).  A compile-time choice
+        // (-DMOPOE_WGRAD_PIPE=0: full rounds, one buffer -- the A/B build): both sets of
+        // instantiations in one translation unit crash this toolchain's register allocator.
+#define WG_ROWS(G_, S_, T_, F_, P_) \
+    wgrad_rows<G_, S_, T_, F_, P_>(gr, xr, G_ ? job.xrows : nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0, rbeg, rend, lane, acc, bsum)
+#define WG_FOLD(G_, S_, T_, P_) (fold ? WG_ROWS(G_, S_, T_, true, P_) : WG_ROWS(G_, S_, T_, false, P_))
+        // MOPOE_WGRAD_PIPE: 0 never, 1 always, 2 four-wave blocks only (one wave per SIMD: no
+        // partner wave whose MFMAs cover a wave's load round trip), 3 those + the 16-row tiles
+        // of eight-wave blocks (a job over twice the batch rows: four rounds per wave)
+#define WG_PIPED(G_, T_) WG_FOLD(G_, 8, T_, true)
+#define WG_PLAIN(G_, T_) WG_FOLD(G_, 16, T_, false)
+#if MOPOE_WGRAD_PIPE == 1
+#define WG_LONG(G_, T_) WG_PIPED(G_, T_)
+#define WG_LONG16(G_, T_) WG_PIPED(G_, T_)
+#elif MOPOE_WGRAD_PIPE == 2
+#define WG_LONG(G_, T_) (kWgWaves == 4 ? WG_PIPED(G_, T_) : WG_PLAIN(G_, T_))
+#define WG_LONG16(G_, T_) WG_LONG(G_, T_)
+#elif MOPOE_WGRAD_PIPE == 3
+#define WG_LONG(G_, T_) (kWgWaves == 4 ? WG_PIPED(G_, T_) : WG_PLAIN(G_, T_))
+#define WG_LONG16(G_, T_) WG_PIPED(G_, T_)
+#else
+#define WG_LONG(G_, T_) WG_PLAIN(G_, T_)
+#define WG_LONG16(G_, T_) WG_PLAIN(G_, T_)
+#endif
+        // (sixteen waves: 128 registers each -- half rounds only, the other waves cover the trips)
         if (th == 16) {   // (only non-gathered operands: the decoder's z and g_xhat)
-            if (half)
-                (fold ? wgrad_rows<false, 8, 1, true>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                        rbeg, rend, lane, acc, bsum)
-                      : wgrad_rows<false, 8, 1, false>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                        rbeg, rend, lane, acc, bsum));
+            if (half || kWgWaves == 16)
+                WG_FOLD(false, 8, 1, false);
             else
-                (fold ? wgrad_rows<false, 16, 1, true>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                         rbeg, rend, lane, acc, bsum)
-                      : wgrad_rows<false, 16, 1, false>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                         rbeg, rend, lane, acc, bsum));
+                WG_LONG16(false, 1);
         } else if (job.xrows) {
-            if (half)
-                (fold ? wgrad_rows<true, 8, 2, true>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                       rbeg, rend, lane, acc, bsum)
-                      : wgrad_rows<true, 8, 2, false>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                       rbeg, rend, lane, acc, bsum));
+            if (half || kWgWaves == 16)
+                WG_FOLD(true, 8, 2, false);
             else
-                (fold ? wgrad_rows<true, 16, 2, true>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                        rbeg, rend, lane, acc, bsum)
-                      : wgrad_rows<true, 16, 2, false>(gr, xr, job.xrows, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                        rbeg, rend, lane, acc, bsum));
+                WG_LONG(true, 2);
         } else {
-            if (half)
-                (fold ? wgrad_rows<false, 8, 2, true>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                        rbeg, rend, lane, acc, bsum)
-                      : wgrad_rows<false, 8, 2, false>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                        rbeg, rend, lane, acc, bsum));
+            if (half || kWgWaves == 16)
+                WG_FOLD(false, 8, 2, false);
             else
-                (fold ? wgrad_rows<false, 16, 2, true>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                         rbeg, rend, lane, acc, bsum)
-                      : wgrad_rows<false, 16, 2, false>(gr, xr, nullptr, job.ldg, job.ldx, gcols, xcols, i0, j0,
-                                         rbeg, rend, lane, acc, bsum));
+                WG_LONG(false, 2);
         }
+#undef WG_LONG
+#undef WG_LONG16
+#undef WG_PIPED
+#undef WG_PLAIN
+#undef WG_FOLD
+#undef WG_ROWS
         GSTAMP(buf.stats, kStampBase + 42, stamp_blk);
         // this wave's partial block -> LDS as [i][j]
         {
@@ -2004,6 +2069,7 @@ struct Knobs {
     bool wgrad_nofold, wgrad_tall;   // MOPOE_WGRAD_NOFOLD / MOPOE_WGRAD_TALL: experiments
     int wb_min_rows;     // MOPOE_WB_MIN_ROWS: rows from which the weight gradients run as split 64 x 64 tiles (kWbMinRows)
     int lin_ks;          // MOPOE_LIN_KS: K parts of the separate encoder-layer launch (0: its own choice; experiments)
+    int lin_xcd;         // MOPOE_LIN_XCD: k_linear_big's XCD-aware tile order (1)
     int lin_big_rows;    // MOPOE_LIN_BIG_ROWS: rows from which the encoder layer runs in 64 x 64 tiles (kLinBigRows)
     int xg_fail_slot;    // MOPOE_TEST_XG_FAIL_SLOT: the exchanging block that reports a failed wait (-1)
 };
@@ -2022,6 +2088,7 @@ Knobs read_knobs() {
     k.q1_idle = num("MOPOE_Q1_IDLE", 2);
     k.lin_big_rows = num("MOPOE_LIN_BIG_ROWS", kLinBigRows);
     k.lin_ks = num("MOPOE_LIN_KS", 0);
+    k.lin_xcd = num("MOPOE_LIN_XCD", 1);
     k.wb_min_rows = num("MOPOE_WB_MIN_ROWS", 4096);   // (= kWbMinRows, mopoe_wgrad_big.inc)
     k.handoff_spins = num("MOPOE_TEST_HANDOFF_SPINS", kHandoffSpins);
     k.fuse_blocks = num("MOPOE_FUSE_BLOCKS", 0);
@@ -2236,6 +2303,7 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s, 
     const int kp = round_up(max_k < kEncKChunk ? max_k : kEncKChunk, 16);
     const size_t lds = ((size_t)kRows * (kp + 4) + kLinRedFloats) * sizeof(float);
     if (la.n >= g_knobs.lin_big_rows) {
+        la.xcd_order = g_knobs.lin_xcd;
         ProfScope ps(MOPOE_KERNEL_LINEAR, s);
         if (la.bf16)
             hipLaunchKernelGGL((k_linear_big<64, true>), dim3(cdiv(max_cols, kBigCols), cdiv(la.n, 64), la.ngroups),
@@ -2749,6 +2817,14 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
         // eight waves per block (half the MFMA chain per wave) for large batches, and from 256
         // rows on while every block still has a CU of its own (two 512-thread blocks do not
         // fit one: registers) -- measured: configs[1] -0.8 us, configs[4] (277 blocks) +2 us
+#if MOPOE_WGRAD_W16
+        // sixteen waves per block from 1,024 rows on while every block has a CU of its own: the
+        // MFMA chain of a block is what it is, but four waves per SIMD cover one another's load
+        // round trips (eight waves: two rounds of requests per wave, each waited for)
+        if (!comm && ka.st.n >= 1024 && grid.x <= (unsigned)device_cus()) {
+            hipLaunchKernelGGL((k_wgrad<16, false>), grid, dim3(1024), 0, s, ka, w);
+        } else
+#endif
         if (ka.st.n > 512 || (ka.st.n >= 256 && grid.x <= 256)) {
             if (comm)
                 hipLaunchKernelGGL((k_wgrad<8, true>), grid, dim3(512), 0, s, ka, w);

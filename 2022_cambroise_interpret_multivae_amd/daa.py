@@ -25,12 +25,15 @@ def _engine(model):
     return eng
 
 
-def _scale(model, name):
+def _scale(model, name, ws=None, m=None, shape=None):
+    """The likelihood's scale of a folded launch: the learnt (1, d) vector, or -- with
+    learn_output_sample_scale (networks.py:57-59,73-75: a logvar HEAD, so the scale is per
+    sample and per forward, which the reference's loop reads as `.scale` of every forward,
+    workflow.py:388-398) -- exp(logvar / 2) of the launch's own logvar-head output, viewed
+    like `loc`."""
     if model.engine.spec.sample_scale:
-        raise NotImplementedError(
-            "the folded DAA forwards return ONE (1, d) scale per modality; with "
-            "learn_output_sample_scale the scale is per sample and per forward -- run the "
-            "forwards one by one (model.forward) for such a model")
+        rows = shape[0] * shape[1]
+        return (ws.lv[m][:rows] * 0.5).exp().view(*shape)
     return (model.engine.views["decoders.%s.logvar" % name] * 0.5).exp()
 
 
@@ -38,7 +41,8 @@ def repeated_reconstructions(model, data, M, sample_latents=True):
     """`M` forwards of the batch `data` as one launch (workflow.py:388-396).
 
     Returns {modality: (loc (M, n, d_m), scale (1, d_m))}: `loc[i]` is
-    `model(data, sample_latents)["rec"][modality].loc` of the i-th forward."""
+    `model(data, sample_latents)["rec"][modality].loc` of the i-th forward; with
+    learn_output_sample_scale `scale` is (M, n, d_m), `scale[i]` that forward's `.scale`."""
     eng = _engine(model)
     names = list(data.keys())
     n = data[names[0]].shape[0]
@@ -49,16 +53,19 @@ def repeated_reconstructions(model, data, M, sample_latents=True):
     for m, name in enumerate(eng.spec.names):
         if name in plan.present:
             d = eng.spec.input_dim[m]
-            out[name] = (ws.loc[m][:M * n].view(M, n, d), _scale(model, name))
+            out[name] = (ws.loc[m][:M * n].view(M, n, d), _scale(model, name, ws, m, (M, n, d)))
     return out
 
 
 def mean_reconstructions(model, data, M):
     """The averages the workflow keeps of the M stochastic forwards
     (workflow.py:397-399): {modality: (mean loc (n, d_m), scale (1, d_m))}.
-    (The mean over M of a scale that does not depend on the sample is the scale.)"""
+    (The mean over M of a scale that does not depend on the sample is the scale; a per-sample
+    scale -- learn_output_sample_scale -- is averaged over the forwards as the reference does,
+    workflow.py:398: (n, d_m).)"""
     rec = repeated_reconstructions(model, data, M, sample_latents=True)
-    return OrderedDict((k, (loc.mean(0), scale)) for k, (loc, scale) in rec.items())
+    return OrderedDict((k, (loc.mean(0), scale.mean(0) if scale.dim() == 3 else scale))
+                       for k, (loc, scale) in rec.items())
 
 
 def perturbed_reconstructions(model, data, scores_values, sampling_strategy="likelihood",

@@ -45,3 +45,17 @@ def _mopoe_knobs(monkeypatch):
     yield
     monkeypatch.undo()
     L.reload_knobs()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _destroy_process_group_at_exit():
+    """Tests that need a one-rank nccl group create it when none exists
+    (test_hip_dp_onecall.py, test_hip_topology.py); whichever came first, the group is
+    destroyed before the interpreter exits (c10d warns about a leaked communicator)."""
+    yield
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

@@ -116,3 +116,46 @@ def test_folded_repeats_through_the_large_batch_encoder_kernel():
         for i in (0, 17, M - 1):
             rep.close("%s/rep%d" % (name, i), rec[name][0][i], one[name].loc, *TOL["loc"])
     rep.finish()
+
+
+def test_daa_helpers_with_the_per_sample_scale_head():
+    """learn_output_sample_scale (networks.py:57-59,73-75): the likelihood's scale is the
+    output of a logvar HEAD, per sample and per forward -- the reference's loop reads
+    `.scale` of every forward (workflow.py:388-398).  The folded launch returns it per repeat
+    (the one combination of two built features that used to raise), equal bit for bit to
+    the separate forwards, and equal to the oracle's."""
+    from importlib import import_module
+    daa = import_module("2022_cambroise_interpret_multivae_amd.daa")
+    cfg = mo.Config(["clinical", "rois"], [7, 444], [3, 20], sample_scale=True)
+    exp = make_experiment(cfg, "cuda")
+    model = exp.models
+    params = mo.init_params(cfg, 0)
+    model.load_state_dict(params)
+    n, M = 12, 5
+    g = torch.Generator().manual_seed(15)
+    data = {"clinical": torch.randn(n, 7, generator=g).cuda(),
+            "rois": torch.randn(n, 444, generator=g).cuda()}
+    rec = daa.repeated_reconstructions(model, data, M, sample_latents=False)
+    one = model(data, sample_latents=False)["rec"]
+    want = mo.forward(params, cfg, {k: v.cpu() for k, v in data.items()}, mo.Noise(tape=[]),
+                      sample_latents=False)["rec"]
+    rep = Report("DAA with the logvar head")
+    for name in data:
+        loc, scale = rec[name]
+        assert loc.shape == scale.shape == (M, n, data[name].shape[1])
+        for i in range(M):
+            assert torch.equal(loc[i], one[name].loc) and torch.equal(scale[i], one[name].scale), name
+        rep.close("loc/" + name, loc[0], want[name][0], *TOL["loc"])
+        rep.close("scale/" + name, scale[0], want[name][1], *TOL["loc"])
+    rep.finish()
+    mean = daa.mean_reconstructions(model, data, 16)
+    for name in data:       # (stochastic: shapes and finiteness; the per-sample scale is averaged)
+        loc, scale = mean[name]
+        assert loc.shape == scale.shape == (n, data[name].shape[1])
+        assert bool(torch.isfinite(loc).all()) and bool((scale > 0).all())
+    sv = torch.randn(3, n, 7, generator=g).cuda()
+    got = daa.perturbed_reconstructions(model, data, sv, "likelihood", sample_latents=False)
+    cdata = data["clinical"].clone()
+    cdata[:, 2] = sv[1, :, 2]
+    ref = model({"clinical": cdata, "rois": data["rois"]}, sample_latents=False)["rec"]["rois"].loc
+    assert torch.equal(got[:, 2, 1], ref)

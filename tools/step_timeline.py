@@ -6,11 +6,14 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mopoe_amd as mm
-n = 256
-spec = mm.ModelSpec(["clinical", "rois"], [7, 444], [3, 20], method="joint_elbo")
+import bench
+cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "C1"]     # C1 | C3 | C5 | N64K
+n = int(sys.argv[2]) if len(sys.argv) > 2 else cfg["batch"]
+spec = bench.make_spec(cfg)
 eng = mm.MoPoEEngine(spec, "cuda", seed=1)
 g = torch.Generator().manual_seed(0)
-pool = [{"clinical": torch.randn(n, 7, generator=g).cuda(), "rois": torch.randn(n, 444, generator=g).cuda()} for _ in range(8)]
+pool = [{k: torch.randn(n, d, generator=g).cuda() for k, d in zip(cfg["names"], cfg["dims"])} for _ in range(8)]
+print("step timeline, %s, %d rows" % (cfg["label"], n))
 for i in range(300): eng.train_step(pool[i % 8])
 torch.cuda.synchronize()
 names = ["k_linear entry", "k_linear row index staged", "k_linear x tile staged", "k_linear MFMA done", "k_linear exit", "k_latent entry", "k_latent stamp0", "k_latent last stage end", "k_latent exit",
