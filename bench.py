@@ -175,10 +175,15 @@ def wants_launcher(args):
 if __name__ == "__main__" and wants_launcher(parse_args()):
     sys.exit(launcher(parse_args(), sys.argv[1:]))     # (before torch / the package are imported)
 
-# The package makes the host wait for the GPU by polling (HSA_ENABLE_INTERRUPT=0, set when it is
-# imported before the HIP runtime starts; MOPOE_HOST_WAIT=interrupt keeps ROCm's default): the
-# benchmark and a training run through run_epochs.train wait the same way.  Reported as
-# config.host_wait.
+# The package makes the host wait for the GPU by polling (HSA_ENABLE_INTERRUPT=0;
+# MOPOE_HOST_WAIT=interrupt keeps ROCm's default) -- its policy, 2022_cambroise_interpret_multivae_amd/
+# _lib.py, so that the benchmark and a training run through run_epochs.train wait the same way.  The
+# ROCm runtime reads the variable when `import torch` loads it (measured: set behind that import, the
+# 20-step region of the driver's invocation reads 37.5 us per step, set in front of it 31-33), so the
+# same policy is applied HERE, ahead of the import; a training script gets it by importing the
+# package (or mopoe_amd) before torch.  Reported as config.host_wait.
+if os.environ.get("MOPOE_HOST_WAIT", "poll") != "interrupt":
+    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
 import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
