@@ -124,14 +124,16 @@ def rank_environments(n, port=None):
              "MOPOE_BENCH_SPAWNED": "1"} for r in range(n)]
 
 
-def launcher(args, argv):
+def launcher(args, argv, cmd=None):
+    """`cmd`: the child command line (tests: a stand-in for a rank); default: this file."""
     import subprocess
     n = args.gpus
     if n < 1:
         sys.exit("--gpus must be >= 1")
     child_argv = [a for a in argv if a != "--launch-dry-run"]
     envs = rank_environments(n, port=29400 if args.launch_dry_run else None)
-    cmd = [sys.executable, os.path.abspath(__file__)] + child_argv
+    if cmd is None:
+        cmd = [sys.executable, os.path.abspath(__file__)] + child_argv
     if args.launch_dry_run:
         print(json.dumps({"launch": "child processes (subprocess.Popen), one per GPU", "n_gpus": n,
                           "cmd": cmd, "ranks": envs}), flush=True)

@@ -64,3 +64,38 @@ def test_a_rank_environment_is_not_relaunched():
     p = _dry("--gpus", "2", "--launch-dry-run",
              env={"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and b"WORLD_SIZE=4" in p.stderr
+
+
+def _launch(n, script):
+    """bench.launcher with stand-in ranks (a python -c script each): what the parent forwards."""
+    import importlib.util
+    import io
+    import contextlib
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)          # (imported, not run: the launcher check needs __main__)
+    args = bench.parse_args(["--gpus", str(n)])
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        rc = bench.launcher(args, ["--gpus", str(n)], cmd=[sys.executable, "-c", script])
+    return rc, out.getvalue()
+
+
+def test_launcher_forwards_rank_zero_and_the_first_failure():
+    """Three stand-in ranks: the parent prints rank 0's LAST non-empty stdout line (the JSON
+    line; other ranks' stdout goes to stderr), hands every child its own rank environment, and
+    returns the first non-zero exit code of any rank."""
+    ok = ("import os, json, sys; r = os.environ['RANK']; print('noise from rank', r); "
+          "print(json.dumps({'rank': r, 'world': os.environ['WORLD_SIZE'], "
+          "'addr': os.environ['MASTER_ADDR'], 'local': os.environ['LOCAL_RANK']}))")
+    rc, text = _launch(3, ok)
+    assert rc == 0
+    lines = [l for l in text.splitlines() if l.strip()]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"rank": "0", "world": "3", "addr": "127.0.0.1", "local": "0"}
+    bad = ok + "; sys.exit(7 if r == '2' else 0)"
+    rc, text = _launch(3, bad)
+    assert rc == 7 and text.strip() == ""       # a failed job prints no line
+    silent = "import sys; sys.exit(0)"
+    rc, text = _launch(2, silent)
+    assert rc == 1 and text.strip() == ""       # rank 0 printed no JSON line: an error, not a success
