@@ -136,7 +136,10 @@ struct alignas(64) EncMod {   // encoder-side stages (heads GEMM, d loss / d h),
     float* heads_out;
     float* g_pre;
     float* g_heads;
-    int pad[12];
+    int kin, a_off, lda;             // heads GEMM: K, the LDS tile it reads as A and its leading
+                                     // dimension -- (256, hs, kLdH), or (d_m, xs, ld_x) for an encoder
+                                     // without a hidden layer (LatentLds::enc0: the heads sit on x)
+    int pad[9];
 };
 
 struct LatentLds {
@@ -205,6 +208,12 @@ struct LatentLds {
     int wd_units[2];                             // 1 KB units (64 pieces of 16 bytes) of it, per present modality
     int wd_valid[2];                             // pieces that hold weights (the rest: zero rows)
     int quad_ok;
+    int enc0;                          // the encoder has NO hidden layer (networks.py:16-20 with
+                                       // num_hidden_layers = 0: the four heads are Linear(d_m, .) on x):
+                                       // no h tiles, no producers, no dL/dh stage; the heads GEMM
+                                       // reads the x tile with K = d_m (generic body only)
+    int enc0_publish;                  // enc0 training step: row group 0 begins the step (there is no
+    mopoe_adam enc0_adam;              // encoder-layer launch to do it) and publishes these Adam records
     int fold_tiles;                    // > 0: `partials` holds this many pre-summed slabs (large batches: k_partials_fold)
     WFrag wf;                                    // fragment-major weight copies (mopoe_buffers.wfrag)
     int rows;                          // batch rows a group owns (16, 8, 4, 2 or 1)
@@ -221,6 +230,7 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
     const int RD = round_up(R * D, 4);  // element-wise arrays keep the tiles 16-byte aligned
     L.rows = R;
     L.rd = RD;
+    L.enc0 = st.pad_ != 0;   // (set by the library on its own copy of the step: mopoe_general_*)
     int hsz = 0, xsz = 0, zcols = 0, klt = st.num_subsets * RD;
     int jobs_of[MOPOE_MAX_MODS] = {0, 0, 0, 0, 0};
     for (int j = 0; j < st.num_jobs; ++j) jobs_of[st.job_mod[j]]++;
@@ -229,7 +239,7 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
         L.xs[i] = xsz;
         L.klt_style[i] = klt;
         if ((st.present_mask >> i) & 1) {
-            hsz += R * kLdH;
+            hsz += L.enc0 ? 0 : R * kLdH;
             xsz += R * ld_x_lds(m, i);
             zcols += round_up(z_dim(m, i), 16);
             klt += round_up(R * m.style_dim[i], 4);
@@ -328,7 +338,8 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
         off += waves * kStatStride;
         L.total = off;
         fits = off * 4 <= 160 * 1024;
-        if (fits || option == 7) break;
+        // (enc0: the heads GEMM reads the x tiles -- they must be in their own area from the start)
+        if (fits || option == (L.enc0 ? 2 : 7)) break;
     }
     {
         int t = 0, sl = cdiv(R * D, kWave);
@@ -471,7 +482,10 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
         f.nblk_h = round_up(f.nh, 16) / 16;
         f.hidden = nullptr;
         f.heads_out = f.g_pre = f.g_heads = nullptr;
-        for (int k = 0; k < 12; ++k) f.pad[k] = 0;
+        f.kin = L.enc0 ? f.d : kHid;
+        f.a_off = L.enc0 ? f.xs : f.hs;
+        f.lda = L.enc0 ? f.ldx : kLdH;
+        for (int k = 0; k < 9; ++k) f.pad[k] = 0;
     }
     {
         int k = 0, q = 0;

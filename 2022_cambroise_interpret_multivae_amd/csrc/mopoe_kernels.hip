@@ -2069,6 +2069,7 @@ struct Knobs {
     bool wgrad_nofold, wgrad_tall;   // MOPOE_WGRAD_NOFOLD / MOPOE_WGRAD_TALL: experiments
     int wb_min_rows;     // MOPOE_WB_MIN_ROWS: rows from which the weight gradients run as split 64 x 64 tiles (kWbMinRows)
     int lin_ks;          // MOPOE_LIN_KS: K parts of the separate encoder-layer launch (0: its own choice; experiments)
+    bool enc0_chain;     // MOPOE_ENC0_CHAIN: an encoder without a hidden layer through the general chain of launches (A/B, tests)
     int lin_xcd;         // MOPOE_LIN_XCD: k_linear_big's XCD-aware tile order (1)
     int lin_big_rows;    // MOPOE_LIN_BIG_ROWS: rows from which the encoder layer runs in 64 x 64 tiles (kLinBigRows)
     int xg_fail_slot;    // MOPOE_TEST_XG_FAIL_SLOT: the exchanging block that reports a failed wait (-1)
@@ -2089,6 +2090,7 @@ Knobs read_knobs() {
     k.lin_big_rows = num("MOPOE_LIN_BIG_ROWS", kLinBigRows);
     k.lin_ks = num("MOPOE_LIN_KS", 0);
     k.lin_xcd = num("MOPOE_LIN_XCD", 1);
+    k.enc0_chain = getenv("MOPOE_ENC0_CHAIN") != nullptr;
     k.wb_min_rows = num("MOPOE_WB_MIN_ROWS", 4096);   // (= kWbMinRows, mopoe_wgrad_big.inc)
     k.handoff_spins = num("MOPOE_TEST_HANDOFF_SPINS", kHandoffSpins);
     k.fuse_blocks = num("MOPOE_FUSE_BLOCKS", 0);
@@ -2144,7 +2146,7 @@ int quad_first_pass_jobs(const mopoe_step& st) {   // jobs of the first decoder 
     return n0;
 }
 bool quad_step(const mopoe_model& mdl, const mopoe_step& st) {
-    if (!g_knobs.quad) return false;
+    if (!g_knobs.quad || st.pad_) return false;   // (pad_: an encoder without a hidden layer -- generic body)
     if (!st.backward || !st.sample || st.joint_mode != MOPOE_JOINT_MIXTURE || st.group_rows != 0 ||
         st.rows_per_group != 0 || mdl.num_mods > 2 || st.num_jobs > 4 || st.n < 4 ||
         // (two decoder passes -- method poe -- gain more from four-row groups than one: measured,
@@ -2427,6 +2429,31 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     int lds = ka.lds.total * (int)sizeof(float);
     if (lds > 160 * 1024)
         return fail(MOPOE_ERR_ARG, "model exceeds the 160 KiB LDS tile budget%s");
+    if (ka.lds.enc0) {
+        // An encoder without a hidden layer: no encoder-layer launch, no producers -- the row
+        // groups are the step's first launch (row group 0 begins the step) and read x themselves.
+        static thread_local int lds_opted0 = 0;
+        if (lds > 64 * 1024 && lds > lds_opted0) {
+            const void* forms[] = {reinterpret_cast<const void*>(k_latent<0>), reinterpret_cast<const void*>(k_latent<1>),
+                                   reinterpret_cast<const void*>(k_latent<2>), reinterpret_cast<const void*>(k_latent<3>)};
+            for (const void* fn : forms) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) return fail(MOPOE_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            }
+            lds_opted0 = lds;
+        }
+        {
+            ProfScope ps(MOPOE_KERNEL_LATENT, s);
+            const dim3 grid(cdiv(ka.st.n, ka.lds.rows)), block(kLatentThreads);
+            switch (launch_form(ka)) {   // (the specialised bodies serve this topology too)
+                case 1: hipLaunchKernelGGL(k_latent<1>, grid, block, (size_t)lds, s, ka); break;
+                case 2: hipLaunchKernelGGL(k_latent<2>, grid, block, (size_t)lds, s, ka); break;
+                case 3: hipLaunchKernelGGL(k_latent<3>, grid, block, (size_t)lds, s, ka); break;
+                default: hipLaunchKernelGGL(k_latent<0>, grid, block, (size_t)lds, s, ka); break;
+            }
+        }
+        return check_launch("k_latent");
+    }
     // Small training batches: encoder layer and per-sample chain in ONE launch
     // (k_fused).  Needs full 16-row groups and the whole grid resident at once to pay.
     const int row_tiles = cdiv(ka.st.n, kRows);
@@ -2612,7 +2639,14 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w, const XgPeer
             jobs[1].wf_off = wf.whf[m], jobs[1].wf_k4 = kHid / 4;
             jobs[2].wf_off = wf.wdf[m], jobs[2].wf_k4 = wf.k4d[m];
         }
-        for (int k = 0; k < 3; ++k) {
+        if (ka.lds.enc0) {   // the heads sit on x: Wh's gradient is g_heads^T x, there is no W1
+            jobs[1].X = ka.buf.x[m];
+            jobs[1].xrows = ka.buf.row_index[m];
+            jobs[1].ldx = jobs[1].xcols = d;
+            jobs[1].xtotal = ka.buf.x_rows[m];
+            jobs[1].wf_off = -1;
+        }
+        for (int k = ka.lds.enc0 ? 1 : 0; k < 3; ++k) {
             WJob& jb = jobs[k];
             // + the bias column, unless the rows are a whole number of tiles (WJob::fold)
             // (small batches only: there the count of blocks decides; with tens of thousands of
@@ -2755,6 +2789,8 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
     ka.st.sample = 1;
     step_layout(ka.mdl, ka.st, ka.lds);
     latent_bind(ka.lds, ka.buf);
+    ka.lds.enc0_publish = adam != nullptr;
+    if (adam) ka.lds.enc0_adam = *adam;
     hipStream_t s = static_cast<hipStream_t>(stream);
     WArgs w;
     // (the exchanging launch does not apply the update itself: whether every block's exchange
@@ -2947,8 +2983,41 @@ int mopoe_general_enc_blocks(const mopoe_topology* tp, const mopoe_step* st, int
     return general_enc_blocks(*tp, *st, train != 0);
 }
 
+// An encoder WITHOUT a hidden layer and nothing else off the default (no hidden decoder layer, no
+// dropout, no logvar head) is the default topology minus its encoder layer: it runs in the row-
+// group kernel (the heads GEMM reads the x tile, K = d_m; no producers, no dL/dh stage) + the
+// weight-gradient launch -- two launches instead of the chain's seven (round 4: 66 -> ~31 us at
+// configs[1]).  Returns true and fills (st2, b2) when the step takes that path: the step with
+// pad_ = 1 (LatentLds::enc0), the buffers with stand-ins for the two tensors of the layer that
+// does not exist (validate() wants them non-null; no kernel touches them).
+static bool enc0_route(const mopoe_model* mdl, const mopoe_topology* tp, const mopoe_step* st,
+                       const mopoe_buffers* buf, bool train, mopoe_step& st2, mopoe_buffers& b2) {
+    if (!mdl || !tp || !st || !buf || g_knobs.enc0_chain) return false;
+    if (tp->enc_layers != 0 || tp->dec_layers != 0 || tp->dropout != 0.f || tp->sample_scale) return false;
+    st2 = *st;
+    st2.pad_ = 1;
+    st2.rows_per_group = 0;
+    st2.backward = train ? 1 : 0;
+    LatentLds L;
+    step_layout(*mdl, st2, L);
+    if (!L.fits || L.rows != kRows || !L.enc0) return false;   // (a general workspace has one slab per 16 rows)
+    b2 = *buf;
+    for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
+        b2.hidden[m] = buf->heads[m];
+        b2.g_pre[m] = buf->g_heads[m];
+    }
+    b2.wgrad_scratch = nullptr;   // (the split weight-gradient launches know the default topology's jobs only)
+    b2.wfrag = nullptr;
+    return true;
+}
+
 int mopoe_general_forward(const mopoe_model* mdl, const mopoe_topology* tp, const mopoe_step* st,
                           const mopoe_buffers* buf, const mopoe_gbuffers* gb, void* stream) {
+    {
+        mopoe_step st2;
+        mopoe_buffers b2;
+        if (enc0_route(mdl, tp, st, buf, false, st2, b2)) return mopoe_forward(mdl, &st2, &b2, stream);
+    }
     GArgs ga;
     GeneralPlan gp;
     if (int rc = general_args(mdl, tp, st, buf, gb, false, ga, gp)) return rc;

@@ -22,6 +22,7 @@ L = mm._lib
 C1 = dict(names=["clinical", "rois"], input_dim=[7, 444], style_dim=[3, 20])
 C5 = dict(names=["clinical", "rois", "snps", "tracts"], input_dim=[7, 444, 128, 64], style_dim=[3, 3, 3, 3])
 TOPOS = [
+    dict(enc_layers=0, dec_layers=0),      # (the row-group kernel on x: no chain of launches)
     dict(enc_layers=2, dec_layers=1),
     dict(enc_layers=0, dec_layers=0, sample_scale=True),
     dict(enc_layers=3, dec_layers=2, dropout=0.3, sample_scale=True),
@@ -164,3 +165,71 @@ def test_one_call_rccl_step_of_a_general_topology():
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert a.adam_steps() == b.adam_steps() == OrderedDict(clinical=3, rois=3)
     one.rccl.close()
+
+
+def _kernel_counts(eng, batches, **kw):
+    L.profile_enable(True)
+    try:
+        for x in batches:
+            eng.train_step(x, **kw)
+        torch.cuda.synchronize()
+        prof = L.profile_read()
+    finally:
+        L.profile_enable(False)
+    return {k: v[0] for k, v in prof.items()}
+
+
+@pytest.mark.parametrize("method,base,present", [("joint_elbo", C1, None), ("poe", C1, None), ("moe", C1, None),
+                                                 ("joint_elbo", C1, ["rois"]), ("joint_elbo", C5, None)])
+def test_encoder_without_hidden_layer_runs_in_the_row_group_kernel(method, base, present, monkeypatch):
+    """num_hidden_layer_encoder = 0 with everything else at its default is the default topology
+    minus its encoder layer: two launches (the row-group kernel reading x with K = d_m, the
+    weight gradients with the heads' job on x) instead of the general chain's seven.  Five
+    free-running steps with injected eps against the oracle step by step, and -- same engine
+    state, same eps -- against the chain of launches (MOPOE_ENC0_CHAIN=1)."""
+    cfg = mo.Config(method=method, **base, enc_layers=0)
+    n = 200
+    monkeypatch.delenv("MOPOE_ENC0_CHAIN", raising=False)
+    spec, eng = make_engine(cfg)
+    _, chain = make_engine(cfg)
+    assert spec.general
+    rep = Report("enc0 %s %s" % (method, present))
+    params = mo.init_params(cfg, 0)
+    state = mo.adam_init(params)
+    steps = 5
+    xs, tapes = [], []
+    for step in range(steps):
+        x = mo.make_inputs(cfg.names, cfg.input_dim, n, seed=40 + step, present=present)
+        noise = mo.Noise(generator=mo.noise_rng(50 + step))
+        params_now = OrderedDict((k, v.cpu().clone()) for k, v in eng.named_params().items())
+        st = {"step": OrderedDict((k, step) for k in params_now if present is None or k.split(".")[1] in present),
+              "exp_avg": OrderedDict((k, v.cpu().clone()) for k, v in spec.param_views(eng.exp_avg).items()),
+              "exp_avg_sq": OrderedDict((k, v.cpu().clone()) for k, v in spec.param_views(eng.exp_avg_sq).items())}
+        for k in params_now:
+            st["step"].setdefault(k, 0)
+        out, grads = mo.train_step(params_now, cfg, x, noise, st)
+        plan, ws = eng.train_step(x, eps=noise.tape)
+        torch.cuda.synchronize()
+        p = "step%d/" % step
+        compare_forward(rep, spec, eng, plan, ws, out, prefix=p, check_scale=False)
+        for k, g in grads.items():
+            rep.close_scaled(p + "grad/" + k, eng.grad_views[k], g, TOL["grad"])
+            rep.close_scaled(p + "exp_avg/" + k, spec.param_views(eng.exp_avg)[k], st["exp_avg"][k], TOL["grad"])
+        xs.append(x)
+        tapes.append(noise.tape)
+        eng.check_valid(sync=True)
+    rep.finish()
+    assert eng.step_count() == steps
+    # the launches: one row-group kernel + one weight-gradient launch per step, no encoder layer
+    counts = _kernel_counts(make_engine(cfg)[1], xs)
+    assert counts["k_latent"] == steps and counts["k_wgrad"] == steps and counts["k_linear"] == 0
+    # ... against the chain on the same inputs: different summation orders, float32 rounding
+    monkeypatch.setenv("MOPOE_ENC0_CHAIN", "1")
+    for x, tape in zip(xs, tapes):
+        chain.train_step(x, eps=tape)
+    torch.cuda.synchronize()
+    chain.check_valid(sync=True)
+    assert _kernel_counts(make_engine(cfg)[1], xs[:1])["k_linear"] > 0      # (the knob: the chain ran)
+    d = (eng.params - chain.params).abs().max().item()
+    assert d < 2e-4, d
+    assert eng.adam_steps() == chain.adam_steps()
