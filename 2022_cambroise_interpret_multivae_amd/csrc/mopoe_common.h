@@ -126,7 +126,10 @@ struct alignas(64) DecJob {   // decoder stages (x_hat and d loss / d z), per de
     int chunks, per, pad2;           // g_z slabs of this job, K blocks of 16 per slab
     float* loc;                      // buffers.loc[mod], buffers.g_xhat[mod]
     float* g_xhat;
-    int pad3[8];
+    float* lv;                       // LatentLds::ss (the decoder's logvar HEAD, networks.py:57-59,73-75):
+    float* g_lv;                     // gbuffers.lv[mod] / g_lv[mod], the head's parameters, and the LDS
+    int off_wlv, off_blv, glv;       // tile [R][ldx] of d loss / d logvar this job's dL/dz stage reads
+    int pad3[1];
 };
 struct alignas(64) EncMod {   // encoder-side stages (heads GEMM, d loss / d h), per modality
     int nh, ldh, off_wh, off_bh;
@@ -208,6 +211,9 @@ struct LatentLds {
     int wd_units[2];                             // 1 KB units (64 pieces of 16 bytes) of it, per present modality
     int wd_valid[2];                             // pieces that hold weights (the rest: zero rows)
     int quad_ok;
+    int ss;                            // learn_output_sample_scale: the likelihood's log-variance is the output
+                                       // of a second decoder head, per sample and feature (generic body only)
+    int glv[MOPOE_MAX_JOBS];           // its gradient tiles [R][ld_x], per decoder job
     int enc0;                          // the encoder has NO hidden layer (networks.py:16-20 with
                                        // num_hidden_layers = 0: the four heads are Linear(d_m, .) on x):
                                        // no h tiles, no producers, no dL/dh stage; the heads GEMM
@@ -230,7 +236,9 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
     const int RD = round_up(R * D, 4);  // element-wise arrays keep the tiles 16-byte aligned
     L.rows = R;
     L.rd = RD;
-    L.enc0 = st.pad_ != 0;   // (set by the library on its own copy of the step: mopoe_general_*)
+    // (pad_: set by the library on its own copy of the step -- mopoe_general_*: bit 0 enc0, bit 1 ss)
+    L.enc0 = (st.pad_ & 1) != 0;
+    L.ss = (st.pad_ & 2) != 0;
     int hsz = 0, xsz = 0, zcols = 0, klt = st.num_subsets * RD;
     int jobs_of[MOPOE_MAX_MODS] = {0, 0, 0, 0, 0};
     for (int j = 0; j < st.num_jobs; ++j) jobs_of[st.job_mod[j]]++;
@@ -318,6 +326,7 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
             L.ev[i] = off;
             off += RD;
         }
+        for (int j = 0; j < MOPOE_MAX_JOBS; ++j) L.glv[j] = 0;
         for (int j = 0; j < st.num_jobs; ++j) {
             const int i = st.job_mod[j];
             L.zj[j] = off;
@@ -332,6 +341,8 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
             off += round_up(R * m.style_dim[i], 4);
             L.stds[j] = off;
             off += round_up(R * m.style_dim[i], 4);
+            L.glv[j] = off;
+            if (L.ss) off += R * ld_x_lds(m, i);
         }
         off = round_up(off, 4);
         L.red = off;
@@ -463,7 +474,10 @@ HD bool latent_lds_layout_rows(const mopoe_model& m, const mopoe_step& st, int w
         f.per = L.job_per[j];
         f.pad2 = 0;
         f.loc = f.g_xhat = nullptr;   // latent_bind()
-        for (int k = 0; k < 8; ++k) f.pad3[k] = 0;
+        f.lv = f.g_lv = nullptr;      // (ss: bound by the caller, with the head's offsets)
+        f.off_wlv = f.off_blv = 0;
+        f.glv = j < MOPOE_MAX_JOBS ? L.glv[j] : 0;
+        f.pad3[0] = 0;
     }
     for (int i = 0; i < MOPOE_MAX_MODS; ++i) {
         EncMod& f = L.em[i];

@@ -2069,7 +2069,8 @@ struct Knobs {
     bool wgrad_nofold, wgrad_tall;   // MOPOE_WGRAD_NOFOLD / MOPOE_WGRAD_TALL: experiments
     int wb_min_rows;     // MOPOE_WB_MIN_ROWS: rows from which the weight gradients run as split 64 x 64 tiles (kWbMinRows)
     int lin_ks;          // MOPOE_LIN_KS: K parts of the separate encoder-layer launch (0: its own choice; experiments)
-    bool enc0_chain;     // MOPOE_ENC0_CHAIN: an encoder without a hidden layer through the general chain of launches (A/B, tests)
+    bool enc0_chain;     // MOPOE_TOPOLOGY_CHAIN: every non-default topology through the general chain of launches (A/B, tests:
+                         // an encoder without a hidden layer and the logvar head otherwise run in the row-group kernel)
     int lin_xcd;         // MOPOE_LIN_XCD: k_linear_big's XCD-aware tile order (1)
     int lin_big_rows;    // MOPOE_LIN_BIG_ROWS: rows from which the encoder layer runs in 64 x 64 tiles (kLinBigRows)
     int xg_fail_slot;    // MOPOE_TEST_XG_FAIL_SLOT: the exchanging block that reports a failed wait (-1)
@@ -2090,7 +2091,7 @@ Knobs read_knobs() {
     k.lin_big_rows = num("MOPOE_LIN_BIG_ROWS", kLinBigRows);
     k.lin_ks = num("MOPOE_LIN_KS", 0);
     k.lin_xcd = num("MOPOE_LIN_XCD", 1);
-    k.enc0_chain = getenv("MOPOE_ENC0_CHAIN") != nullptr;
+    k.enc0_chain = getenv("MOPOE_TOPOLOGY_CHAIN") != nullptr;
     k.wb_min_rows = num("MOPOE_WB_MIN_ROWS", 4096);   // (= kWbMinRows, mopoe_wgrad_big.inc)
     k.handoff_spins = num("MOPOE_TEST_HANDOFF_SPINS", kHandoffSpins);
     k.fuse_blocks = num("MOPOE_FUSE_BLOCKS", 0);
@@ -2356,6 +2357,9 @@ int launch_form(const KArgs& ka) {
         return 0;   // (four-row groups: the caller picks form 4)
     for (int k = 0; k < st.num_subsets; ++k)
         if (st.sub_kind[k] == MOPOE_SUB_SLICES) return 0;
+    // (pad_ bit 1, the decoder's logvar head: form 6 = form 1 + the head, fused launch only; else generic)
+    if (st.pad_ & 2)
+        return (mdl.num_mods <= 2 && L.single_pass && L.s3_nt == 2 && L.xs_early && st.num_jobs <= 2 && !L.enc0) ? 6 : 0;
     if (mdl.num_mods <= 2 && L.single_pass && L.s3_nt == 2 && L.xs_early && st.num_jobs <= 2) return 1;
     if (mdl.num_mods <= 2 && !L.single_pass && L.s3_nt == 2 && L.xs_early && st.num_jobs <= 4) return 2;
     if (mdl.num_mods <= 4 && L.single_pass && L.s3_nt == 4 && !L.xs_early && st.num_jobs <= 4) return 3;
@@ -2369,6 +2373,7 @@ const void* fused_form_fn(int form) {
         case 3: return reinterpret_cast<const void*>(k_fused<3>);
         case 4: return reinterpret_cast<const void*>(k_fused<4>);
         case 5: return reinterpret_cast<const void*>(k_fused<5>);
+        case 6: return reinterpret_cast<const void*>(k_fused<6>);
         default: return reinterpret_cast<const void*>(k_fused<0>);
     }
 }
@@ -2563,7 +2568,8 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
         if (lds > 64 * 1024 && lds > lds_opted_f) {
             const void* forms[] = {reinterpret_cast<const void*>(k_fused<0>), reinterpret_cast<const void*>(k_fused<1>),
                                    reinterpret_cast<const void*>(k_fused<2>), reinterpret_cast<const void*>(k_fused<3>),
-                                   reinterpret_cast<const void*>(k_fused<4>), reinterpret_cast<const void*>(k_fused<5>)};
+                                   reinterpret_cast<const void*>(k_fused<4>), reinterpret_cast<const void*>(k_fused<5>),
+                                   reinterpret_cast<const void*>(k_fused<6>)};
             for (const void* fn : forms) {
                 hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 if (e != hipSuccess) return fail(MOPOE_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -2583,6 +2589,7 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
                 case 1: hipLaunchKernelGGL(k_fused<1>, grid, block, (size_t)lds, s, fa); break;
                 case 2: hipLaunchKernelGGL(k_fused<2>, grid, block, (size_t)lds, s, fa); break;
                 case 3: hipLaunchKernelGGL(k_fused<3>, grid, block, (size_t)lds, s, fa); break;
+                case 6: hipLaunchKernelGGL(k_fused<6>, grid, block, (size_t)lds, s, fa); break;
                 default: hipLaunchKernelGGL(k_fused<0>, grid, block, (size_t)lds, s, fa); break;
             }
         }
@@ -2646,8 +2653,20 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w, const XgPeer
             jobs[1].xtotal = ka.buf.x_rows[m];
             jobs[1].wf_off = -1;
         }
-        for (int k = ka.lds.enc0 ? 1 : 0; k < 3; ++k) {
-            WJob& jb = jobs[k];
+        WJob head = jobs[2];   // (ss: the logvar head's weights -- G = d loss / d logvar, X = z like the decoder's)
+        if (ka.lds.ss) {
+            int j0 = 0;
+            while (j0 < st.num_jobs && st.job_mod[j0] != m) ++j0;
+            if (j0 < st.num_jobs) {
+                head.G = ka.lds.dj[j0].g_lv;
+                head.off_w = ka.lds.dj[j0].off_wlv;
+                head.off_b = ka.lds.dj[j0].off_blv;
+                head.wf_off = -1;
+            }
+        }
+        for (int k = ka.lds.enc0 ? 1 : 0; k < (ka.lds.ss && njobs_m > 0 ? 4 : 3); ++k) {
+            WJob jb_local = k < 3 ? jobs[k] : head;
+            WJob& jb = jb_local;
             // + the bias column, unless the rows are a whole number of tiles (WJob::fold)
             // (small batches only: there the count of blocks decides; with tens of thousands of
             //  rows every block is MFMA-bound and the extra adds make the folded ones the last)
@@ -2665,7 +2684,8 @@ void build_wargs(const KArgs& ka, const mopoe_adam* adam, WArgs& w, const XgPeer
     int lb = 0;
     for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
         w.lvo_block_begin[m] = lb;
-        if (m < mdl.num_mods && ((st.present_mask >> m) & 1)) lb += cdiv(mdl.input_dim[m], 64);
+        // (with the logvar head there is no learnt logvar vector and no partial sums of its gradient)
+        if (!ka.lds.ss && m < mdl.num_mods && ((st.present_mask >> m) & 1)) lb += cdiv(mdl.input_dim[m], 64);
     }
     w.lvo_block_begin[MOPOE_MAX_MODS] = lb;
     w.lvo_blocks = lb;
@@ -2772,8 +2792,24 @@ namespace {
 // `fuse_adam`: the weight-gradient launch applies the update itself (the one-rank step).
 // Otherwise the launches stop at the gradients -- with `adam` non-NULL the step's first
 // kernel still publishes its Adam records for the k_adam launch that follows an exchange.
+// the logvar head's tensors and parameter offsets into the decoder jobs' records (LatentLds::ss)
+int bind_logvar_head(KArgs& ka, const mopoe_topology* tp, const mopoe_gbuffers* gb, bool train) {
+    if (!ka.lds.ss) return 0;
+    if (!tp || !gb) return fail(MOPOE_ERR_ARG, "the logvar head needs its topology and buffers%s");
+    for (int j = 0; j < ka.st.num_jobs; ++j) {
+        const int m = ka.st.job_mod[j];
+        if (!gb->lv[m] || (train && !gb->g_lv[m])) return fail(MOPOE_ERR_ARG, "null logvar head buffer%s");
+        ka.lds.dj[j].lv = gb->lv[m];
+        ka.lds.dj[j].g_lv = gb->g_lv[m];
+        ka.lds.dj[j].off_wlv = tp->off_wlv[m];
+        ka.lds.dj[j].off_blv = tp->off_blv[m];
+    }
+    return 0;
+}
+
 int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* buf,
-                    const mopoe_adam* adam, mopoe_comm* comm, bool fuse_adam, void* stream) {
+                    const mopoe_adam* adam, mopoe_comm* comm, bool fuse_adam, void* stream,
+                    const mopoe_topology* tp = nullptr, const mopoe_gbuffers* gb = nullptr) {
     if (int rc = validate(mdl, st, buf, true)) return rc;
     if (adam && (!buf->exp_avg || !buf->exp_avg_sq))
         return fail(MOPOE_ERR_ARG, "null Adam state%s");
@@ -2789,6 +2825,7 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
     ka.st.sample = 1;
     step_layout(ka.mdl, ka.st, ka.lds);
     latent_bind(ka.lds, ka.buf);
+    if (int rc = bind_logvar_head(ka, tp, gb, true)) return rc;
     ka.lds.enc0_publish = adam != nullptr;
     if (adam) ka.lds.enc0_adam = *adam;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2983,40 +3020,55 @@ int mopoe_general_enc_blocks(const mopoe_topology* tp, const mopoe_step* st, int
     return general_enc_blocks(*tp, *st, train != 0);
 }
 
-// An encoder WITHOUT a hidden layer and nothing else off the default (no hidden decoder layer, no
-// dropout, no logvar head) is the default topology minus its encoder layer: it runs in the row-
-// group kernel (the heads GEMM reads the x tile, K = d_m; no producers, no dL/dh stage) + the
-// weight-gradient launch -- two launches instead of the chain's seven (round 4: 66 -> ~31 us at
-// configs[1]).  Returns true and fills (st2, b2) when the step takes that path: the step with
-// pad_ = 1 (LatentLds::enc0), the buffers with stand-ins for the two tensors of the layer that
-// does not exist (validate() wants them non-null; no kernel touches them).
-static bool enc0_route(const mopoe_model* mdl, const mopoe_topology* tp, const mopoe_step* st,
-                       const mopoe_buffers* buf, bool train, mopoe_step& st2, mopoe_buffers& b2) {
-    if (!mdl || !tp || !st || !buf || g_knobs.enc0_chain) return false;
-    if (tp->enc_layers != 0 || tp->dec_layers != 0 || tp->dropout != 0.f || tp->sample_scale) return false;
+// Two topologies off the default run in the row-group kernel instead of the general chain of
+// launches (round 4), alone or together:
+//   * an encoder WITHOUT a hidden layer (the default topology minus its encoder layer: the heads
+//     GEMM reads the x tile, K = d_m; no producers, no dL/dh stage) -- pad_ bit 0, LatentLds::enc0;
+//   * the decoder's logvar HEAD (learn_output_sample_scale: a second output head, per-sample
+//     scale; the default's fused launch with two sets of decoder accumulators, a second dL/dz
+//     contribution and a fourth weight-gradient job per modality) -- pad_ bit 1, LatentLds::ss.
+// Hidden decoder layers, more than one hidden encoder layer and dropout take the chain.  Returns
+// true and fills (st2, b2) when the step takes the kernel: the step with its pad_ bits, the
+// buffers with the hidden layer's tensors where the default topology has them (or stand-ins for
+// the layer that does not exist: validate() wants them non-null, no kernel touches them).
+static bool rowgroup_route(const mopoe_model* mdl, const mopoe_topology* tp, const mopoe_step* st,
+                           const mopoe_buffers* buf, const mopoe_gbuffers* gb, bool train,
+                           mopoe_step& st2, mopoe_buffers& b2) {
+    if (!mdl || !tp || !st || !buf || !gb || g_knobs.enc0_chain) return false;
+    if (tp->enc_layers > 1 || tp->dec_layers != 0 || tp->dropout != 0.f) return false;
+    const int bits = (tp->enc_layers == 0 ? 1 : 0) | (tp->sample_scale ? 2 : 0);
+    if (!bits) return false;
+    int npres = 0;
+    for (int m = 0; m < mdl->num_mods; ++m) npres += (st->present_mask >> m) & 1;
+    if ((bits & 2) && 4 * npres > 3 * MOPOE_MAX_MODS) return false;   // (k_wgrad's job table)
     st2 = *st;
-    st2.pad_ = 1;
+    st2.pad_ = bits;
     st2.rows_per_group = 0;
     st2.backward = train ? 1 : 0;
     LatentLds L;
     step_layout(*mdl, st2, L);
-    if (!L.fits || L.rows != kRows || !L.enc0) return false;   // (a general workspace has one slab per 16 rows)
+    if (!L.fits || L.rows != kRows) return false;   // (a general workspace has one slab per 16 rows)
+    if ((bits & 2) && L.s3_nt != 2) return false;    // (the head's decoder unit exists in its two-tile form)
     b2 = *buf;
     for (int m = 0; m < MOPOE_MAX_MODS; ++m) {
-        b2.hidden[m] = buf->heads[m];
-        b2.g_pre[m] = buf->g_heads[m];
+        const bool layer = tp->enc_layers == 1 && m < mdl->num_mods;
+        b2.hidden[m] = layer ? gb->enc_act[m][0] : buf->heads[m];
+        b2.g_pre[m] = layer ? gb->g_enc[m][0] : buf->g_heads[m];
+        if (layer && ((st->present_mask >> m) & 1) && (!b2.hidden[m] || (train && !b2.g_pre[m]))) return false;
     }
     b2.wgrad_scratch = nullptr;   // (the split weight-gradient launches know the default topology's jobs only)
     b2.wfrag = nullptr;
     return true;
 }
+int forward_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* buf, void* stream,
+                 const mopoe_topology* tp, const mopoe_gbuffers* gb);
 
 int mopoe_general_forward(const mopoe_model* mdl, const mopoe_topology* tp, const mopoe_step* st,
                           const mopoe_buffers* buf, const mopoe_gbuffers* gb, void* stream) {
     {
         mopoe_step st2;
         mopoe_buffers b2;
-        if (enc0_route(mdl, tp, st, buf, false, st2, b2)) return mopoe_forward(mdl, &st2, &b2, stream);
+        if (rowgroup_route(mdl, tp, st, buf, gb, false, st2, b2)) return forward_impl(mdl, &st2, &b2, stream, tp, gb);
     }
     GArgs ga;
     GeneralPlan gp;
@@ -3114,6 +3166,11 @@ int mopoe_latent_lds_bytes(const mopoe_model* mdl, const mopoe_step* st) {
 
 int mopoe_forward(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* buf,
                   void* stream) {
+    return forward_impl(mdl, st, buf, stream, nullptr, nullptr);
+}
+
+int forward_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buffers* buf, void* stream,
+                 const mopoe_topology* tp, const mopoe_gbuffers* gb) {
     if (int rc = validate(mdl, st, buf, false)) return rc;
     KArgs ka;
     ka.mdl = *mdl;
@@ -3122,6 +3179,7 @@ int mopoe_forward(const mopoe_model* mdl, const mopoe_step* st, const mopoe_buff
     ka.st.backward = 0;
     step_layout(ka.mdl, ka.st, ka.lds);
     latent_bind(ka.lds, ka.buf);
+    if (int rc = bind_logvar_head(ka, tp, gb, false)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (buf->wgrad_scratch && cdiv(ka.st.n, ka.lds.rows) >= 8 * kFoldSlices &&
         buf->wgrad_scratch_floats < (int64_t)kFoldSlices * ka.lds.part_stride)
