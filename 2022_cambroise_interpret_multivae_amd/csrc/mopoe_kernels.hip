@@ -2071,6 +2071,7 @@ struct Knobs {
     int lin_ks;          // MOPOE_LIN_KS: K parts of the separate encoder-layer launch (0: its own choice; experiments)
     bool enc0_chain;     // MOPOE_TOPOLOGY_CHAIN: every non-default topology through the general chain of launches (A/B, tests:
                          // an encoder without a hidden layer and the logvar head otherwise run in the row-group kernel)
+    bool uniform_ks;     // MOPOE_UNIFORM_KS: one K-part count for all wide modalities in the fused launch (A/B)
     int lin_xcd;         // MOPOE_LIN_XCD: k_linear_big's XCD-aware tile order (1)
     int lin_big_rows;    // MOPOE_LIN_BIG_ROWS: rows from which the encoder layer runs in 64 x 64 tiles (kLinBigRows)
     int xg_fail_slot;    // MOPOE_TEST_XG_FAIL_SLOT: the exchanging block that reports a failed wait (-1)
@@ -2091,6 +2092,7 @@ Knobs read_knobs() {
     k.lin_big_rows = num("MOPOE_LIN_BIG_ROWS", kLinBigRows);
     k.lin_ks = num("MOPOE_LIN_KS", 0);
     k.lin_xcd = num("MOPOE_LIN_XCD", 1);
+    k.uniform_ks = getenv("MOPOE_UNIFORM_KS") != nullptr;
     k.enc0_chain = getenv("MOPOE_TOPOLOGY_CHAIN") != nullptr;
     k.wb_min_rows = num("MOPOE_WB_MIN_ROWS", 4096);   // (= kWbMinRows, mopoe_wgrad_big.inc)
     k.handoff_spins = num("MOPOE_TEST_HANDOFF_SPINS", kHandoffSpins);
@@ -2515,11 +2517,48 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     if (oversub) hd.ks = oversub_ks;
     while (hd.ks > 1 && !oversub && nlin_for(hd.ks) + groups > fuse_blocks()) hd.ks /= 2;
     int nlin = nlin_for(hd.ks);
+    // K parts per modality.  One count for all is what fits when it is 4; with fewer, the parts
+    // are dealt where the chains are (round 4): every modality starts with one 256-column block per
+    // row tile, and the one with the longest chain K / parts doubles its parts while the grid
+    // still fits -- configs[4] (7 / 444 / 128 / 64 columns, 32 row tiles): 4 parts for the
+    // 444-column modality and 1 for the others = 224 producers, longest chain 128 columns' worth
+    // instead of 222 with two parts for all three.  (Not for an over-subscribed launch: its rule
+    // counts blocks against 1.8 x the CUs.)
+    int ksz[MOPOE_MAX_MODS];
+    for (int z = 0; z < MOPOE_MAX_MODS; ++z) ksz[z] = (z < la.ngroups && !narrow(z)) ? hd.ks : 1;
+    if (!oversub && hd.ks < 4 && !g_knobs.uniform_ks) {
+        int plan[MOPOE_MAX_MODS], blocks = la.ngroups * row_tiles;
+        for (int z = 0; z < MOPOE_MAX_MODS; ++z) plan[z] = 1;
+        for (;;) {
+            int worst = -1, cost = 0;
+            for (int z = 0; z < la.ngroups; ++z)
+                if (!narrow(z) && plan[z] < 4 && la.g[z].K / plan[z] > cost) {
+                    cost = la.g[z].K / plan[z];
+                    worst = z;
+                }
+            if (worst < 0 || blocks + plan[worst] * row_tiles + groups > fuse_blocks()) break;
+            // (a modality that is not the longest chain any more is not split further)
+            int longest = 0;
+            for (int z = 0; z < la.ngroups; ++z) longest = la.g[z].K / plan[z] > longest ? la.g[z].K / plan[z] : longest;
+            if (cost < longest) break;
+            blocks += plan[worst] * row_tiles;
+            plan[worst] *= 2;
+        }
+        int chain_u = 0, chain_p = 0;
+        for (int z = 0; z < la.ngroups; ++z) {
+            chain_u = la.g[z].K / ksz[z] > chain_u ? la.g[z].K / ksz[z] : chain_u;
+            chain_p = la.g[z].K / plan[z] > chain_p ? la.g[z].K / plan[z] : chain_p;
+        }
+        if (chain_p < chain_u && blocks + groups <= fuse_blocks()) {
+            for (int z = 0; z < la.ngroups; ++z) ksz[z] = plan[z];
+            nlin = blocks;
+        }
+    }
     int blocks_per_tile[MOPOE_MAX_MODS];
     for (int z = 0; z < MOPOE_MAX_MODS; ++z) {
-        const bool one = hd.ks == 1 || (z < la.ngroups && narrow(z));
-        hd.tiles[z] = one ? kLatentWaves : kLatentWaves / hd.ks;
-        blocks_per_tile[z] = z < la.ngroups ? (one ? 1 : hd.ks) : 0;
+        const bool one = ksz[z] == 1;
+        hd.tiles[z] = one ? kLatentWaves : kLatentWaves / ksz[z];
+        blocks_per_tile[z] = z < la.ngroups ? ksz[z] : 0;
     }
     // the widest modalities get 32-column blocks while the grid still fits the chip:
     // a block's MFMA chain is its tiles x K, and the row groups wait for the slowest
@@ -2597,7 +2636,34 @@ int launch_forward_part(const KArgs& ka, const mopoe_adam* adam, hipStream_t s) 
     }
     // (a step the fused launch could take, kept in three launches: the fused form's K split)
     const bool fusable = (ka.lds.rows == kRows || quad) && ka.st.group_rows == 0 && nlin + groups <= fuse_blocks();
-    if (int rc = launch_linear(la, maxd, kHid, s, fusable ? hd.ks : 0)) return rc;
+    {
+        // (per-modality K parts: one encoder-layer launch per part count, so that every modality's
+        //  sums come out as in the fused launch)
+        bool uniform = true;
+        for (int z = 0; z < la.ngroups; ++z) uniform &= ksz[z] == hd.ks || narrow(z);
+        if (!fusable || uniform) {
+            if (int rc = launch_linear(la, maxd, kHid, s, fusable ? hd.ks : 0)) return rc;
+        } else {
+            bool first = true;
+            for (int k = 1; k <= 4; k *= 2) {
+                LinArgs sub = la;
+                sub.ngroups = 0;
+                int kmax = 1;
+                for (int z = 0; z < la.ngroups; ++z)
+                    if (ksz[z] == k) {
+                        sub.g[sub.ngroups++] = la.g[z];
+                        kmax = la.g[z].K > kmax ? la.g[z].K : kmax;
+                    }
+                if (!sub.ngroups) continue;
+                if (!first) {   // (the step begins once)
+                    sub.counters = nullptr;
+                    sub.publish = 0;
+                }
+                first = false;
+                if (int rc = launch_linear(sub, kmax, kHid, s, k)) return rc;
+            }
+        }
+    }
 
     static thread_local int lds_opted = 0;
     if (lds > 64 * 1024 && lds > lds_opted) {
