@@ -9,10 +9,9 @@ import os
 # Host-side waits.  A training step here is ~30 us of GPU work: when the host does wait for the
 # GPU (torch.cuda.synchronize, a blocking copy) ROCm's default -- sleep until an interrupt --
 # costs 20-60 us per wait, polling ~5 us (HSA_ENABLE_INTERRUPT=0; the runtime reads it once, when
-# `import torch` loads it -- measured: bench.py's 20-step region reads 37.5 us per step with the
-# variable set behind that import and 31-33 us with it set in front -- so import this package, or
-# the mopoe_amd alias, BEFORE torch for the policy to take effect; bench.py applies it ahead of its
-# own torch import).  The package asks for polling unless the user decided otherwise: an explicit
+# it starts: set it -- or import this package / the mopoe_amd alias -- before the process's first
+# HIP call; bench.py applies the same policy ahead of its own torch import).  The package asks for
+# polling unless the user decided otherwise: an explicit
 # HSA_ENABLE_INTERRUPT wins, MOPOE_HOST_WAIT=interrupt keeps ROCm's default.  bench.py and
 # run_epochs.train therefore wait the same way (bench.py reports it as config.host_wait).
 if os.environ.get("MOPOE_HOST_WAIT", "poll") != "interrupt":

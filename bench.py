@@ -10,10 +10,13 @@ on): 2-modality joint_elbo MoPoE, input dims 7+444, latent 20, factorized style 
 encoder/decoder forward, MoPoE fusion, joint ELBO, full backward, (gradient exchange
 when N > 1), Adam, and the step's scalar log written by the kernel into pinned host
 memory (the reference logs every step, run_epochs.py:184).  W untimed steps, then
-EXACTLY K timed steps between barrier + synchronize pairs, max over ranks -- done twice:
-as the first GPU work of the process (`cold_start`: at --steps 20 --warmup 5 the whole
-timed region is under a millisecond of a chip that was idle, and reads ~25 % slow), and
-again after --settle (3000) untimed steps, which is `value`: what training runs at.
+EXACTLY K timed steps between barrier + synchronize pairs, max over ranks -- as the first
+GPU work of the process (`cold_start`: at --steps 20 --warmup 5 the whole timed region is
+under a millisecond of a chip that was idle, and reads ~25 % slow), and again after --settle
+(3000) untimed steps, which is `value`: what training runs at.  For K <= 200 that second
+region is timed five times back to back and `value` is the median (a 0.6 ms region between
+two synchronisations read 30.7 .. 42.7 us per step over four runs on one box); all samples
+are in the line.
 
 For N > 1 the driver launches one rank per GPU with torch.distributed.run; ranks are
 data-parallel replicas (weak scaling: 256 samples per GPU per step) that exchange the
@@ -179,11 +182,11 @@ if __name__ == "__main__" and wants_launcher(parse_args()):
 
 # The package makes the host wait for the GPU by polling (HSA_ENABLE_INTERRUPT=0;
 # MOPOE_HOST_WAIT=interrupt keeps ROCm's default) -- its policy, 2022_cambroise_interpret_multivae_amd/
-# _lib.py, so that the benchmark and a training run through run_epochs.train wait the same way.  The
-# ROCm runtime reads the variable when `import torch` loads it (measured: set behind that import, the
-# 20-step region of the driver's invocation reads 37.5 us per step, set in front of it 31-33), so the
-# same policy is applied HERE, ahead of the import; a training script gets it by importing the
-# package (or mopoe_amd) before torch.  Reported as config.host_wait.
+# _lib.py, so that the benchmark and a training run through run_epochs.train wait the same way.  It
+# is applied here as well, ahead of `import torch` (the runtime reads the variable once, when it
+# starts).  What it buys: the first synchronisations of a process (cold_start 34-36 us per step
+# against 49-70 with interrupts, same box); the 20-step figure itself is noise-limited either
+# way (30.7-42.7 polling, 31.7-32.1 interrupts over six runs).  Reported as config.host_wait.
 if os.environ.get("MOPOE_HOST_WAIT", "poll") != "interrupt":
     os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
 import torch  # noqa: E402
@@ -760,22 +763,31 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(warmup, steps, first=0):
+    pos = {"n": 0}       # steps enqueued so far (the batch and the log slot of a step follow from it)
+
+    def timed(warmup, steps):
         ws = None
-        for i in range(warmup):
-            step(first + i)
+        for _ in range(warmup):
+            step(pos["n"])
+            pos["n"] += 1
         barrier()
         t0 = time.perf_counter()
-        for i in range(steps):
-            ws = step(first + warmup + i)
+        for _ in range(steps):
+            ws = step(pos["n"])
+            pos["n"] += 1
         barrier()
         return time.perf_counter() - t0, ws
 
-    # Timed twice: first thing (a chip that has idled: clocks still ramping, caches and TLBs
-    # cold -- reported as `cold_start`), then again after SETTLE untimed steps: the W warm-up
-    # steps and EXACTLY K timed steps as asked, on a chip at its working clocks.  `value` is
-    # the second, which is what a training run sees after its first few milliseconds.
+    # Timed first thing (a chip that has idled: clocks still ramping, caches and TLBs cold --
+    # reported as `cold_start`), then again after SETTLE untimed steps: the W warm-up steps and
+    # EXACTLY K timed steps as asked, on a chip at its working clocks -- `value`, what a training
+    # run sees after its first few milliseconds.  A region of 20 steps is 0.6 ms between two
+    # synchronisations: on ONE box four runs of the driver's invocation read 30.7, 31.3, 35.5 and
+    # 42.7 us per step (round 4), so for K <= 200 the region is timed REPS = 5 times back to back
+    # (each exactly K steps between barrier + synchronize pairs) and `value` is the MEDIAN; every
+    # sample is in the line (`value_samples_ms_per_step`).
     SETTLE = args.settle
+    REPS = 5 if args.steps <= 200 else 1
     cold = {}
 
     def measure():
@@ -783,8 +795,13 @@ def main():
         cold["dt"] = dt0
         # (the settling steps are timed as one region too: `long_run` -- what a K of thousands
         #  reads; a 20-step region of 0.7 ms carries its two synchronisations, ~80 us)
-        cold["settle_dt"], _ = timed(0, SETTLE, first=args.warmup + args.steps)
-        return timed(args.warmup, args.steps, first=args.warmup + args.steps + SETTLE)
+        cold["settle_dt"], _ = timed(0, SETTLE)
+        samples, ws = [], None
+        for r in range(REPS):
+            dt_r, ws = timed(args.warmup if r == 0 else 0, args.steps)
+            samples.append(dt_r)
+        cold["samples"] = samples
+        return sorted(samples)[len(samples) // 2], ws
 
     dt, ws = measure()
     if comm is not None:
@@ -818,9 +835,11 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_identical = bool(lo.item() == hi.item())
     if dist is not None:
-        t = torch.tensor([dt, cold["dt"], cold["settle_dt"]], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, cold["dt"], cold["settle_dt"] = (float(v) for v in t.tolist())
+        t = torch.tensor([cold["dt"], cold["settle_dt"]] + cold["samples"], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)     # (every region: the slowest rank's time)
+        v = [float(x) for x in t.tolist()]
+        cold["dt"], cold["settle_dt"], cold["samples"] = v[0], v[1], v[2:]
+        dt = sorted(cold["samples"])[len(cold["samples"]) // 2]
     loss = float(ws.stats[0].item())
     eng.check_valid(sync=True)     # (raises if any step of the timed region was invalid)
     if dist is not None:           # replicas must still be identical
@@ -831,7 +850,7 @@ def main():
         if lo.item() != hi.item():
             sys.exit("data-parallel replicas drifted apart")
     if not args.no_log_copy:   # the host ring must have received the same scalar
-        host = float(log_ring[(2 * (args.warmup + args.steps) + SETTLE - 1) % 8][0])
+        host = float(log_ring[(pos["n"] - 1) % 8][0])
         if host != loss:
             sys.exit("pinned-host log %r != device scalar %r" % (host, loss))
     if not (loss == loss and abs(loss) < 1e9):
@@ -875,8 +894,11 @@ def main():
                    "host_wait": "polling (HSA_ENABLE_INTERRUPT=0)"
                                 if os.environ.get("HSA_ENABLE_INTERRUPT") == "0" else "interrupts",
                    "settle_steps": SETTLE,
-                   # `value` is the SECOND timing of the same W + K steps: what ran before it
+                   # what ran before the region(s) `value` is read from
                    "warmup_effective": 2 * args.warmup + args.steps + SETTLE,
+                   "timing": ("median of %d regions of exactly %d steps, each between barrier + "
+                              "synchronize pairs, back to back" % (REPS, args.steps)) if REPS > 1 else
+                             "one region of exactly %d steps" % args.steps,
                    "final_loss": round(loss, 3)},
         "cold_start": {"ms_per_step": round(1e3 * cold["dt"] / args.steps, 5),
                        "value": round(BATCH * world * args.steps / cold["dt"], 1),
@@ -892,7 +914,8 @@ def main():
                            "what": "the settling steps timed as one region (same loop, same "
                                    "barriers): the figure a K of thousands reads"}
 
-    nxt = 2 * (args.warmup + args.steps) + SETTLE
+    out["value_samples_ms_per_step"] = [round(1e3 * x / args.steps, 5) for x in cold["samples"]]
+    nxt = pos["n"]
     if rank == 0 and not args.no_roofline:
         # instrumented re-run of the same K steps: HIP events around every
         # launch, on the launch stream
