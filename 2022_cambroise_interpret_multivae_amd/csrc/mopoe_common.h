@@ -842,6 +842,31 @@ DEV f32x4 glb_b4_nt(rsrc_t r, int ldw, int K, int j0, int kb, int lane) {
     return v;
 }
 
+// Philox4x32-10 -> four uniforms in (0, 1): the dropout keep decisions (keep iff u >= p)
+DEV f32x4 philox_uniform4(uint64_t seed, uint32_t step, uint32_t stream, uint32_t quad) {
+    uint32_t c0 = quad, c1 = stream, c2 = step, c3 = 0x64726f70u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    f32x4 u;
+    u[0] = ((c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    u[1] = ((c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    u[2] = ((c2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    u[3] = ((c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return u;
+}
+
 // Philox4x32-10 -> FOUR standard normals per call (two Box-Muller pairs; the angle goes
 // through v_sin_f32 / v_cos_f32, which take revolutions: no range reduction).  Counter =
 // (quad, stream, step, tag), key = seed; element idx of a stream is component idx & 3 of

@@ -150,6 +150,26 @@ struct LinArgs {
     LinGroup g[MOPOE_MAX_MODS];
 };
 
+// Dropout(p) behind a hidden layer of a general topology, applied in the layer's own epilogue
+// (k_linear_drop; mopoe_general.inc: the keep decisions are g_dropout's -- the same Philox
+// stream and element numbering, or the injected mask)
+struct LinDropGroup {
+    const float* keep;     // injected keep mask (n, ncols) of 0 / 1, or nullptr: Philox
+    uint32_t stream;       // Philox stream of this (modality, stack, layer)
+    uint32_t row0;         // first row's number inside the stream
+    int32_t rows, pad;     // rows of this group's activation (the launch's n is the groups' maximum)
+};
+struct LinDrop {
+    float p, scale;        // scale = 1 / (1 - p) in float32, as ATen's noise.div_(1 - p)
+    uint64_t seed;
+    const int32_t* counters;   // the step number: [BEGUN], or [DONE] + 1 in the launch that begins the step
+    LinDropGroup g[MOPOE_MAX_MODS];
+};
+struct LinDropArgs {
+    LinArgs la;
+    LinDrop d;
+};
+
 // Adam scalars of step t, torch.optim.Adam (_single_tensor_adam) semantics:
 // python-double scalars applied to float32 tensors.
 struct AdamCoef {
@@ -326,9 +346,9 @@ constexpr int kLinRedFloats = 4 * kWave * 4;  // partial tiles handed over throu
 // accumulation chain of a 16x16 tile over K = 444 is 111 issues of 32 cycles, and a
 // small batch has too few tiles to keep the chip's SIMDs busy otherwise; KS = 1 for
 // large ones, where a workgroup should cover as many columns per staged x tile as it can.
-template <int KS>
+template <int KS, bool DROP>
 DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int* rowsel,
-                     int tid, int lane, int wave) {
+                     int tid, int lane, int wave, const LinDrop* dr, uint32_t step_no) {
     constexpr int CH = 8;      // W fragments per wave and batch
     constexpr int kStage = 8;  // float4 loads in flight per thread while staging
     const int N = a.n, K = g.K;
@@ -338,6 +358,30 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
     const int j0 = (blockIdx.x * (4 / KS) + tile) * 16;
     const rsrc_t xr = make_rsrc(g.X, (size_t)g.xrows * g.ldx * sizeof(float));
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    // Dropout: the tile's 16 x 16 keep factors are ONE Philox quad (four columns of a row) per
+    // lane, drawn here by the tile's last K part -- whose wave has nothing to do at the end --
+    // while the x tile is on its way, and left in the fourth slot of the partial tiles' LDS area
+    // (slots t KS .. t KS + KS - 2 carry tile t's partials).  (Drawn in the epilogue by the one
+    // wave that stores the tile, a quad per ELEMENT, the 32-bit multiplies of four Philox calls
+    // were 1.1 us at the end of every block: 9.1 us per layer against 6.6 + 4.5 apart.)
+    float* const dropk = lds + kRows * (round_up(min(K, kEncKChunk), 16) + 4) + (tile * KS + KS - 1) * kWave * 4;
+    if (DROP && part == KS - 1) {
+        const LinDropGroup dg = dr->g[blockIdx.z];
+        const int pr = lane >> 2, pq = lane & 3;
+        const int gn = n0 + pr, c0 = j0 + 4 * pq;
+        f32x4 kp = {1.f, 1.f, 1.f, 1.f};
+        if (gn < dg.rows && c0 < g.ncols) {   // (ncols % 4 == 0: hidden layers are 256 wide)
+            if (dg.keep) {
+                kp = *reinterpret_cast<const f32x4*>(dg.keep + (size_t)gn * g.ncols + c0);
+            } else {
+                const f32x4 u = philox_uniform4(dr->seed, step_no, dg.stream,
+                                                (dg.row0 + (uint32_t)gn) * (uint32_t)(g.ncols >> 2) + (uint32_t)(c0 >> 2));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kp[e] = u[e] >= dr->p ? 1.f : 0.f;
+            }
+        }
+        *reinterpret_cast<f32x4*>(dropk + lane * 4) = kp;   // [row pr][column 4 pq ..]
+    }
     for (int kc0 = 0; kc0 < K; kc0 += kEncKChunk) {
         const int Kc = min(kEncKChunk, K - kc0);
         const int Kp = round_up(Kc, 16);
@@ -425,12 +469,19 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
     const int col = j0 + (lane & 15);
     if (col >= g.ncols) return;
     const float bias = g.b ? g.b[col] : 0.f;
+    float keep[4] = {1.f, 1.f, 1.f, 1.f};
+    if (DROP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) keep[r] = dropk[(4 * (lane >> 4) + r) * 16 + (lane & 15)];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int gn = n0 + 4 * (lane >> 4) + r;
         if (gn < N) {
-            const float v = acc[r] + bias;
-            g.Y[(size_t)gn * g.ldy + col] = g.relu ? fmaxf(v, 0.f) : v;
+            float v = acc[r] + bias;
+            v = g.relu ? fmaxf(v, 0.f) : v;
+            if (DROP) v = v * (keep[r] * dr->scale);
+            g.Y[(size_t)gn * g.ldy + col] = v;
         }
     }
 }
@@ -442,16 +493,20 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
 #ifndef MOPOE_LIN_MINW
 #define MOPOE_LIN_MINW 2
 #endif
-template <int KS>
-__global__ __launch_bounds__(256, MOPOE_LIN_MINW) void k_linear(const LinArgs a_by_value) {
-    (void)a_by_value;  // read in place (see k_latent)
-    const LinArgs& a = *(const LinArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+template <int KS, bool DROP>
+DEV void linear_block(const LinArgs& a, const LinDrop* dr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     // wave id as a provably wave-uniform scalar (guide T20): everything derived
     // from it stays in SGPRs and buffer descriptors need no waterfall loop
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     GSTAMP(a.counters, kCtrStamp + 11, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
+    // (the number of the step this launch belongs to, requested here and used in the epilogue: the
+    //  launch that begins the step cannot wait for its block 0 -- latent_body's rule, [DONE] + 1)
+    uint32_t step_no = 0;
+    if (DROP)
+        step_no = a.counters ? (uint32_t)__builtin_nontemporal_load(dr->counters + MOPOE_CTR_STEPS_DONE) + 1u
+                             : (uint32_t)__builtin_nontemporal_load(dr->counters + MOPOE_CTR_STEPS_BEGUN);
     if (a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
         step_begin(a.counters, a.num_mods, a.publish ? &a.adam : nullptr);
     }
@@ -467,8 +522,21 @@ __global__ __launch_bounds__(256, MOPOE_LIN_MINW) void k_linear(const LinArgs a_
     }
     GSTAMP(a.counters, kCtrStamp + 13, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
     const int* rs = gather ? rowsel : nullptr;
-    linear_tile<KS>(a, g, lds, rs, tid, lane, wave);
+    linear_tile<KS, DROP>(a, g, lds, rs, tid, lane, wave, dr, step_no);
     GSTAMP(a.counters, kCtrStamp + 12, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, MOPOE_LIN_MINW) void k_linear(const LinArgs a_by_value) {
+    (void)a_by_value;  // read in place (see k_latent)
+    linear_block<KS, false>(*(const LinArgs*)__builtin_amdgcn_kernarg_segment_ptr(), nullptr);
+}
+// ... followed by Dropout(p) (a hidden layer of a general topology: mopoe_general.inc)
+template <int KS>
+__global__ __launch_bounds__(256, MOPOE_LIN_MINW) void k_linear_drop(const LinDropArgs a_by_value) {
+    (void)a_by_value;
+    const LinDropArgs& a = *(const LinDropArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    linear_block<KS, true>(a.la, &a.d);
 }
 
 // ---------------------------------------------------------------------------
@@ -2071,6 +2139,8 @@ struct Knobs {
     int lin_ks;          // MOPOE_LIN_KS: K parts of the separate encoder-layer launch (0: its own choice; experiments)
     bool enc0_chain;     // MOPOE_TOPOLOGY_CHAIN: every non-default topology through the general chain of launches (A/B, tests:
                          // an encoder without a hidden layer and the logvar head otherwise run in the row-group kernel)
+    bool drop_apart;     // MOPOE_DROPOUT_APART: Dropout as a launch of its own behind every hidden layer (A/B)
+    bool nn_wide;        // MOPOE_NN_WIDE: g_gemm_nn with one wave per tile at every batch size (A/B)
     bool uniform_ks;     // MOPOE_UNIFORM_KS: one K-part count for all wide modalities in the fused launch (A/B)
     int lin_xcd;         // MOPOE_LIN_XCD: k_linear_big's XCD-aware tile order (1)
     int lin_big_rows;    // MOPOE_LIN_BIG_ROWS: rows from which the encoder layer runs in 64 x 64 tiles (kLinBigRows)
@@ -2093,6 +2163,8 @@ Knobs read_knobs() {
     k.lin_ks = num("MOPOE_LIN_KS", 0);
     k.lin_xcd = num("MOPOE_LIN_XCD", 1);
     k.uniform_ks = getenv("MOPOE_UNIFORM_KS") != nullptr;
+    k.nn_wide = getenv("MOPOE_NN_WIDE") != nullptr;
+    k.drop_apart = getenv("MOPOE_DROPOUT_APART") != nullptr;
     k.enc0_chain = getenv("MOPOE_TOPOLOGY_CHAIN") != nullptr;
     k.wb_min_rows = num("MOPOE_WB_MIN_ROWS", 4096);   // (= kWbMinRows, mopoe_wgrad_big.inc)
     k.handoff_spins = num("MOPOE_TEST_HANDOFF_SPINS", kHandoffSpins);
@@ -2303,11 +2375,15 @@ int latent_lds_bytes(const mopoe_model& mdl, const mopoe_step& st) {
 
 // ks_hint: the K split of the fused launch for the same step (its sums must come out the
 // same whichever form runs: tests/test_hip_fused.py), or 0 for this launch's own choice
-int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s, int ks_hint = 0) {
+// drop: Dropout(p) in the epilogue (k_linear_drop; the caller keeps to batches below
+// Knobs::lin_big_rows, the 64-row tiles have no such epilogue)
+int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s, int ks_hint = 0,
+                  const LinDrop* drop = nullptr) {
     LinArgs la = la_in;
     const int kp = round_up(max_k < kEncKChunk ? max_k : kEncKChunk, 16);
     const size_t lds = ((size_t)kRows * (kp + 4) + kLinRedFloats) * sizeof(float);
     if (la.n >= g_knobs.lin_big_rows) {
+        if (drop) return fail(MOPOE_ERR_ARG, "internal: no dropout epilogue in the 64-row tiles%s");
         la.xcd_order = g_knobs.lin_xcd;
         ProfScope ps(MOPOE_KERNEL_LINEAR, s);
         if (la.bf16)
@@ -2328,7 +2404,17 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s, 
     {
         ProfScope ps(MOPOE_KERNEL_LINEAR, s);
         const dim3 grid(cdiv(max_cols, 64 / ks), cdiv(la.n, kRows), la.ngroups);
-        if (ks == 4)
+        if (drop) {
+            LinDropArgs da;
+            da.la = la;
+            da.d = *drop;
+            if (ks == 4)
+                hipLaunchKernelGGL(k_linear_drop<4>, grid, dim3(256), lds, s, da);
+            else if (ks == 2)
+                hipLaunchKernelGGL(k_linear_drop<2>, grid, dim3(256), lds, s, da);
+            else
+                hipLaunchKernelGGL(k_linear_drop<1>, grid, dim3(256), lds, s, da);
+        } else if (ks == 4)
             hipLaunchKernelGGL(k_linear<4>, grid, dim3(256), lds, s, la);
         else if (ks == 2)
             hipLaunchKernelGGL(k_linear<2>, grid, dim3(256), lds, s, la);

@@ -63,16 +63,21 @@ def test_device_drawn_dropout_masks():
     mo.forward(mo.init_params(cfg, 0), cfg, x, eps, train=False)
     kept = []
     for step in range(2):
+        w0 = {n: (a.views["encoders.%s.shared_encoder.0.weight" % n].clone(),
+                  a.views["encoders.%s.shared_encoder.0.bias" % n].clone()) for n in cfg.names}
         (_, wa), (_, wb) = a.train_step(x, eps=eps.tape), b.train_step(x, eps=eps.tape)
         torch.cuda.synchronize()
-        for m in range(2):
-            pre, act = wa.enc_pre0[m], wa.enc_act[m][0]
-            live = pre > 0
+        for m, name in enumerate(cfg.names):
+            # (Dropout sits in the layer's own epilogue: the pre-dropout activation is not kept,
+            #  so it is recomputed here from the weights the step read)
+            pre = torch.relu(x[name].cuda().double() @ w0[name][0].double().t() + w0[name][1].double()).float()
+            act = wa.enc_act[m][0]
+            live = pre > 1e-4
             keep = (act != 0)[live].float().mean().item()
             assert abs(keep - 0.75) < 0.01, keep
             on = live & (act != 0)
-            assert torch.allclose(act[on], pre[on] * (1.0 / 0.75), rtol=1e-6)
-            assert not (act[~live] != 0).any()
+            assert torch.allclose(act[on], pre[on] * (1.0 / 0.75), rtol=1e-4, atol=1e-6)
+            assert not (act[pre == 0] != 0).any()
             assert torch.equal(wa.enc_act[m][1], wb.enc_act[m][1])     # twin: the same masks
             kept.append((act != 0).clone())
         assert torch.equal(a.params, b.params)
@@ -179,6 +184,28 @@ def _kernel_counts(eng, batches, **kw):
     return {k: v[0] for k, v in prof.items()}
 
 
+def _knife_edge_units(params, cfg, x):
+    """Hidden units of the first encoder layer whose pre-activation is within float32 rounding
+    of zero for some row of this batch: whether such a (row, unit) passes the ReLU is decided by
+    the summation order of K products -- the oracle's and the kernel's both round correctly and
+    may differ -- and ONE row's contribution then enters or leaves that unit's weight and bias
+    gradient (seen: unit 82 of 'tracts', float64 pre-activation -5.7e-10, kernel +9.7e-8).
+    {gradient key: [unit, ...]} of the units to leave out of the comparison."""
+    out = {}
+    if cfg.enc_layers == 0:
+        return out
+    for name in cfg.names:
+        if name not in x:
+            continue
+        w = "encoders.%s.shared_encoder.0.weight" % name
+        b = w.replace("weight", "bias")
+        pre = x[name].double() @ params[w].double().t() + params[b].double()
+        units = (pre.abs().min(0).values < 2e-6).nonzero().flatten().tolist()
+        if units:
+            out[w] = out[b] = units
+    return out
+
+
 ROWGROUP_TOPOS = [dict(enc_layers=0), dict(sample_scale=True), dict(enc_layers=0, sample_scale=True)]
 
 
@@ -210,14 +237,18 @@ def test_topologies_that_run_in_the_row_group_kernel(topo, method, base, present
                                   for k in params_now),
               "exp_avg": OrderedDict((k, v.cpu().clone()) for k, v in spec.param_views(eng.exp_avg).items()),
               "exp_avg_sq": OrderedDict((k, v.cpu().clone()) for k, v in spec.param_views(eng.exp_avg_sq).items())}
+        edge = _knife_edge_units(params_now, cfg, x)
         out, grads = mo.train_step(params_now, cfg, x, noise, st)
         plan, ws = eng.train_step(x, eps=noise.tape)
         torch.cuda.synchronize()
         p = "step%d/" % step
         compare_forward(rep, spec, eng, plan, ws, out, prefix=p, check_scale=False)
         for k, g in grads.items():
-            rep.close_scaled(p + "grad/" + k, eng.grad_views[k], g, TOL["grad"])
-            rep.close_scaled(p + "exp_avg/" + k, spec.param_views(eng.exp_avg)[k], st["exp_avg"][k], TOL["grad"])
+            got, avg = eng.grad_views[k].clone(), spec.param_views(eng.exp_avg)[k].clone()
+            for u in edge.get(k, ()):       # (the ReLU decision there is rounding's: either answer is right)
+                got[u], avg[u] = g[u], st["exp_avg"][k][u]
+            rep.close_scaled(p + "grad/" + k, got, g, TOL["grad"])
+            rep.close_scaled(p + "exp_avg/" + k, avg, st["exp_avg"][k], TOL["grad"])
         if cfg.sample_scale:    # the head's (N, d) scale of THIS forward (before the update)
             res = eng.results(plan, ws)
             for k in res["rec"]:
