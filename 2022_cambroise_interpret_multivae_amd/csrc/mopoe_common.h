@@ -650,6 +650,24 @@ DEV void lds_add(float* p, float v) {
 // torch's sign(): 0 at 0 (the gradient torch.abs hands back)
 DEV float sign_of(float v) { return v > 0.f ? 1.f : v < 0.f ? -1.f : 0.f; }
 
+// A launch's argument block was written by the host a moment ago: the first touch of each of its
+// 64-byte lines misses every cache, and a kernel that walks its tables (subset records, job
+// records, buffer pointers) pays those misses one behind the other, a trip to memory each.
+// Here the block's waves touch every line once, side by side, before the first table is
+// needed: one trip, after which the scalar cache has the block.  (BYTES, NW compile-time.)
+template <int BYTES, int NW>
+DEV void warm_args(const void* base, int wave) {
+    typedef __attribute__((address_space(4))) const int* cptr;
+    cptr p = (cptr)(uintptr_t)base;
+    int acc = 0;
+#pragma unroll
+    for (int i = 0; i < (BYTES / 64 + NW - 1) / NW; ++i) {
+        const int line = wave + i * NW;
+        acc += p[(line * 64 < BYTES ? line : 0) * 16];
+    }
+    __asm__ volatile("" ::"s"(acc));
+}
+
 DEV float wave_sum(float v) {
     auto dpp_add = [](float x, auto ctrl) __attribute__((always_inline)) {
         constexpr int kCtrl = decltype(ctrl)::value;
