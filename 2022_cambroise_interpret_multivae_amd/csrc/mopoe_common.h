@@ -50,7 +50,16 @@ HD int lvo_part_off(const mopoe_model& m, int i) {
     return off;
 }
 HD int lvo_slot_stride(const mopoe_model& m, int i) { return round_up(m.input_dim[i], 4); }
-HD int partials_stride(const mopoe_model& m) { return lvo_part_off(m, m.num_mods); }
+// behind them: a word per (modality, decoder job, tile of 16 output columns) -- the NLL partial of
+// that tile of the row group, left by the output layer's epilogue of a general topology's
+// training step and added up, in tile order, by the launch behind it (mopoe_general.inc)
+HD int nll_tiles_off(const mopoe_model& m, int i) {
+    int off = lvo_part_off(m, m.num_mods);
+    for (int k = 0; k < i; ++k) off += kLvoSlots * cdiv(m.input_dim[k], 16);
+    return off;
+}
+HD int nll_tiles_slot_stride(const mopoe_model& m, int i) { return cdiv(m.input_dim[i], 16); }
+HD int partials_stride(const mopoe_model& m) { return round_up(nll_tiles_off(m, m.num_mods), 4); }
 
 // Fragment-major weight copies of the four-row form (latent_body FORM 4).  The 4x4x1 MFMA
 // wants, per K step, column l of a 64-column tile in lane l; with nn.Linear's (out, in)

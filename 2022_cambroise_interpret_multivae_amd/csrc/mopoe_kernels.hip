@@ -170,6 +170,30 @@ struct LinDropArgs {
     LinDrop d;
 };
 
+// The likelihood of a general topology's training step in the OUTPUT layer's epilogue
+// (k_linear_nll; mopoe_general.inc): the tile has loc in registers -- NLL terms, d loss / d loc
+// and the column sums of d loss / d logvar are made there, the tile's NLL partial is left in
+// the row group's slab (nll_tiles_off) for the next launch to add up.
+constexpr int kNllSlots = 2;   // decoder passes of a modality (joint + unimodal): kLvoSlots
+struct LinNllGroup {
+    const float* x;            // (x_rows, ncols) input of the modality
+    const int32_t* row_index;  // gather (n_step) or nullptr
+    const float* lvo;          // (ncols) learnt logvar
+    float* g_xhat;             // out (rows, ncols)
+    int32_t x_rows, rows;      // rows = slots * n_step of this group
+    int32_t lvo_part[kNllSlots], tile_off[kNllSlots];
+    float coef[kNllSlots];     // nll_coef / n_step of the slot's job
+};
+struct LinNll {
+    int32_t n_step, laplace, part_stride, pad;   // n_step % 16 == 0 where a modality has two slots
+    float* partials;
+    LinNllGroup g[MOPOE_MAX_MODS];
+};
+struct LinNllArgs {
+    LinArgs la;
+    LinNll q;
+};
+
 // Adam scalars of step t, torch.optim.Adam (_single_tensor_adam) semantics:
 // python-double scalars applied to float32 tensors.
 struct AdamCoef {
@@ -346,9 +370,12 @@ constexpr int kLinRedFloats = 4 * kWave * 4;  // partial tiles handed over throu
 // accumulation chain of a 16x16 tile over K = 444 is 111 issues of 32 cycles, and a
 // small batch has too few tiles to keep the chip's SIMDs busy otherwise; KS = 1 for
 // large ones, where a workgroup should cover as many columns per staged x tile as it can.
-template <int KS, bool DROP>
+constexpr int kEpiPlain = 0, kEpiDrop = 1, kEpiNll = 2;
+template <int KS, int EPI>
 DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int* rowsel,
-                     int tid, int lane, int wave, const LinDrop* dr, uint32_t step_no) {
+                     int tid, int lane, int wave, const void* ex, uint32_t step_no) {
+    constexpr bool DROP = EPI == kEpiDrop;
+    const LinDrop* dr = (const LinDrop*)ex;
     constexpr int CH = 8;      // W fragments per wave and batch
     constexpr int kStage = 8;  // float4 loads in flight per thread while staging
     const int N = a.n, K = g.K;
@@ -467,6 +494,63 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
             acc += *reinterpret_cast<const f32x4*>(red + ((wave + p - 1) * kWave + lane) * 4);
     }
     const int col = j0 + (lane & 15);
+    if (EPI == kEpiNll) {
+        // Modality.calc_log_prob (modalities/modality.py:42-45) of this tile: g_nll's arithmetic
+        if (j0 >= g.ncols) return;   // (wave-uniform)
+        const LinNll& nq = *(const LinNll*)ex;
+        const LinNllGroup& ng = nq.g[blockIdx.z];
+        const int slot = n0 / nq.n_step;          // (a tile lies inside one slot)
+        const int g0 = n0 - slot * nq.n_step;     // its first row inside the slot
+        float* part = nq.partials + (size_t)(g0 >> 4) * nq.part_stride;
+        const float coef = slot == 0 ? ng.coef[0] : ng.coef[1];
+        const bool laplace = nq.laplace != 0, cv = col < g.ncols;
+        const int q = lane >> 4, dm = g.ncols;
+        const float bias = (g.b && cv) ? g.b[col] : 0.f;
+        const float l = cv ? ng.lvo[col] : 0.f;
+        float xv[4];
+        bool rv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gn = g0 + 4 * q + r;        // row inside the slot
+            rv[r] = cv & (gn < nq.n_step) & (n0 + 4 * q + r < ng.rows);
+            const int src = ng.row_index ? ng.row_index[rv[r] ? gn : 0] : gn;
+            xv[r] = (rv[r] && (unsigned)src < (unsigned)ng.x_rows) ? ng.x[(size_t)src * dm + col] : 0.f;
+        }
+        const float inv_var = expf(laplace ? -0.5f * l : -l);
+        float term = 0.f, glv = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t o = (size_t)(n0 + 4 * q + r) * dm + col;
+            const float loc = acc[r] + bias;
+            const float diff = xv[r] - loc;
+            float qq, gg, gl, t;
+            if (laplace) {   // scale b = e^(lv / 2): |diff| / b + lv / 2 + log 2
+                qq = fabsf(diff) * inv_var;
+                t = qq + 0.5f * l + kLog2;
+                gl = 0.5f - 0.5f * qq;
+                gg = -sign_of(diff) * inv_var * coef;
+            } else {         // diff^2 / (2 var) + lv / 2 + log sqrt(2 pi)
+                qq = 0.5f * diff * diff * inv_var;
+                t = qq + 0.5f * l + kHalfLog2Pi;
+                gl = 0.5f - qq;
+                gg = -diff * inv_var * coef;
+            }
+            if (rv[r]) {
+                g.Y[o] = loc;   // (ldy == ncols)
+                ng.g_xhat[o] = gg;
+                term += t;
+                glv += gl;
+            }
+        }
+        // d loss / d logvar of the group's rows, per column: this lane's four rows + the three
+        // other row quarters of the same column (lanes c + 16, + 32, + 48)
+        glv += __shfl_xor(glv, 16);
+        glv += __shfl_xor(glv, 32);
+        if (q == 0 && cv) part[(slot == 0 ? ng.lvo_part[0] : ng.lvo_part[1]) + col] = glv * coef;
+        const float ts = wave_sum(term);
+        if (lane == 0) part[(slot == 0 ? ng.tile_off[0] : ng.tile_off[1]) + (j0 >> 4)] = ts;
+        return;
+    }
     if (col >= g.ncols) return;
     const float bias = g.b ? g.b[col] : 0.f;
     float keep[4] = {1.f, 1.f, 1.f, 1.f};
@@ -493,8 +577,10 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
 #ifndef MOPOE_LIN_MINW
 #define MOPOE_LIN_MINW 2
 #endif
-template <int KS, bool DROP>
-DEV void linear_block(const LinArgs& a, const LinDrop* dr) {
+template <int KS, int EPI>
+DEV void linear_block(const LinArgs& a, const void* ex) {
+    constexpr bool DROP = EPI == kEpiDrop;
+    const LinDrop* dr = (const LinDrop*)ex;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     // wave id as a provably wave-uniform scalar (guide T20): everything derived
@@ -522,21 +608,28 @@ DEV void linear_block(const LinArgs& a, const LinDrop* dr) {
     }
     GSTAMP(a.counters, kCtrStamp + 13, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
     const int* rs = gather ? rowsel : nullptr;
-    linear_tile<KS, DROP>(a, g, lds, rs, tid, lane, wave, dr, step_no);
+    linear_tile<KS, EPI>(a, g, lds, rs, tid, lane, wave, ex, step_no);
     GSTAMP(a.counters, kCtrStamp + 12, a.counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (a.ngroups > 1 ? 1 : 0) && tid == 0);
 }
 
 template <int KS>
 __global__ __launch_bounds__(256, MOPOE_LIN_MINW) void k_linear(const LinArgs a_by_value) {
     (void)a_by_value;  // read in place (see k_latent)
-    linear_block<KS, false>(*(const LinArgs*)__builtin_amdgcn_kernarg_segment_ptr(), nullptr);
+    linear_block<KS, kEpiPlain>(*(const LinArgs*)__builtin_amdgcn_kernarg_segment_ptr(), nullptr);
 }
 // ... followed by Dropout(p) (a hidden layer of a general topology: mopoe_general.inc)
 template <int KS>
 __global__ __launch_bounds__(256, MOPOE_LIN_MINW) void k_linear_drop(const LinDropArgs a_by_value) {
     (void)a_by_value;
     const LinDropArgs& a = *(const LinDropArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    linear_block<KS, true>(a.la, &a.d);
+    linear_block<KS, kEpiDrop>(a.la, &a.d);
+}
+// ... the output layer of a training step, followed by the likelihood (LinNll)
+template <int KS>
+__global__ __launch_bounds__(256, MOPOE_LIN_MINW) void k_linear_nll(const LinNllArgs a_by_value) {
+    (void)a_by_value;
+    const LinNllArgs& a = *(const LinNllArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    linear_block<KS, kEpiNll>(a.la, &a.q);
 }
 
 // ---------------------------------------------------------------------------
@@ -2140,6 +2233,7 @@ struct Knobs {
     bool enc0_chain;     // MOPOE_TOPOLOGY_CHAIN: every non-default topology through the general chain of launches (A/B, tests:
                          // an encoder without a hidden layer and the logvar head otherwise run in the row-group kernel)
     bool drop_apart;     // MOPOE_DROPOUT_APART: Dropout as a launch of its own behind every hidden layer (A/B)
+    bool nll_apart;      // MOPOE_NLL_APART: the likelihood as a launch of its own in a training step (A/B)
     bool nn_wide;        // MOPOE_NN_WIDE: g_gemm_nn with one wave per tile at every batch size (A/B)
     bool uniform_ks;     // MOPOE_UNIFORM_KS: one K-part count for all wide modalities in the fused launch (A/B)
     int lin_xcd;         // MOPOE_LIN_XCD: k_linear_big's XCD-aware tile order (1)
@@ -2164,6 +2258,7 @@ Knobs read_knobs() {
     k.lin_xcd = num("MOPOE_LIN_XCD", 1);
     k.uniform_ks = getenv("MOPOE_UNIFORM_KS") != nullptr;
     k.nn_wide = getenv("MOPOE_NN_WIDE") != nullptr;
+    k.nll_apart = getenv("MOPOE_NLL_APART") != nullptr;
     k.drop_apart = getenv("MOPOE_DROPOUT_APART") != nullptr;
     k.enc0_chain = getenv("MOPOE_TOPOLOGY_CHAIN") != nullptr;
     k.wb_min_rows = num("MOPOE_WB_MIN_ROWS", 4096);   // (= kWbMinRows, mopoe_wgrad_big.inc)
@@ -2378,12 +2473,12 @@ int latent_lds_bytes(const mopoe_model& mdl, const mopoe_step& st) {
 // drop: Dropout(p) in the epilogue (k_linear_drop; the caller keeps to batches below
 // Knobs::lin_big_rows, the 64-row tiles have no such epilogue)
 int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s, int ks_hint = 0,
-                  const LinDrop* drop = nullptr) {
+                  const LinDrop* drop = nullptr, const LinNll* nll = nullptr) {
     LinArgs la = la_in;
     const int kp = round_up(max_k < kEncKChunk ? max_k : kEncKChunk, 16);
     const size_t lds = ((size_t)kRows * (kp + 4) + kLinRedFloats) * sizeof(float);
     if (la.n >= g_knobs.lin_big_rows) {
-        if (drop) return fail(MOPOE_ERR_ARG, "internal: no dropout epilogue in the 64-row tiles%s");
+        if (drop || nll) return fail(MOPOE_ERR_ARG, "internal: no dropout / likelihood epilogue in the 64-row tiles%s");
         la.xcd_order = g_knobs.lin_xcd;
         ProfScope ps(MOPOE_KERNEL_LINEAR, s);
         if (la.bf16)
@@ -2404,7 +2499,17 @@ int launch_linear(const LinArgs& la_in, int max_k, int max_cols, hipStream_t s, 
     {
         ProfScope ps(MOPOE_KERNEL_LINEAR, s);
         const dim3 grid(cdiv(max_cols, 64 / ks), cdiv(la.n, kRows), la.ngroups);
-        if (drop) {
+        if (nll) {
+            LinNllArgs na;
+            na.la = la;
+            na.q = *nll;
+            if (ks == 4)
+                hipLaunchKernelGGL(k_linear_nll<4>, grid, dim3(256), lds, s, na);
+            else if (ks == 2)
+                hipLaunchKernelGGL(k_linear_nll<2>, grid, dim3(256), lds, s, na);
+            else
+                hipLaunchKernelGGL(k_linear_nll<1>, grid, dim3(256), lds, s, na);
+        } else if (drop) {
             LinDropArgs da;
             da.la = la;
             da.d = *drop;
