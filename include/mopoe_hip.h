@@ -332,7 +332,10 @@ int mopoe_wfrag_refresh(const mopoe_model* model, const mopoe_buffers* buf, void
  * below the size from which the split weight-gradient launches pay; a forward-only
  * step -- step->backward == 0 -- of fewer than 512 row groups) */
 int64_t mopoe_wgrad_scratch_floats(const mopoe_model* model, const mopoe_step* step);
-/* floats per row group in `partials` */
+/* floats per row group in `partials` (the scalar partial sums, the d loss / d logvar column
+ * sums per decoder pass and -- since the general topologies' likelihood runs in the output
+ * layer's epilogue -- a word per decoder pass and tile of 16 output columns; always size
+ * `partials` by this call) */
 int mopoe_partials_stride(const mopoe_model* model);
 /* row groups the fused per-sample kernel cuts the batch into for this step
  * (= the number of partial slabs the caller provides): ceil(n / rows), rows = 16
