@@ -172,6 +172,43 @@ def test_one_call_rccl_step_of_a_general_topology():
     one.rccl.close()
 
 
+@pytest.mark.parametrize("method,base", [("joint_elbo", C1), ("poe", C1), ("joint_elbo", C5)])
+def test_epilogue_forms_of_the_chain_equal_the_separate_launches(method, base, monkeypatch):
+    """The chain's second cut moved Dropout into the hidden layers'
+    epilogues, the likelihood into the output layer's, and split the backward-data GEMM's K over
+    a block's waves.  Same seed, same batches, device-drawn noise and masks: Dropout apart
+    (MOPOE_DROPOUT_APART) is the same arithmetic on the same Philox draws -- bit-identical
+    gradients and scalars; the likelihood apart / one wave per backward-data tile
+    (MOPOE_NLL_APART, MOPOE_NN_WIDE) differ in summation order only."""
+    import mopoe_amd as mm
+    cfg = mo.Config(method=method, **base, enc_layers=2, dec_layers=1, dropout=0.2)
+    xs = [mo.make_inputs(cfg.names, cfg.input_dim, 208, seed=70 + i) for i in range(4)]
+
+    def run(**env):
+        for k in ("MOPOE_DROPOUT_APART", "MOPOE_NLL_APART", "MOPOE_NN_WIDE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        spec, _ = make_engine(cfg)
+        eng = mm.MoPoEEngine(spec, "cuda", seed=4242)
+        eng.load_params(mo.init_params(cfg, 0))
+        out = []
+        for x in xs:     # (gradients only: Adam turns the rounding noise of a ~0 gradient into a step)
+            plan, ws = eng.train_step(x, apply_adam=False)
+            torch.cuda.synchronize()
+            out.append((eng.grads.clone(), ws.stats[:L.NUM_STATS].clone()))
+        eng.check_valid(sync=True)
+        return out
+
+    base_run = run()
+    for (g0, s0), (g1, s1) in zip(base_run, run(MOPOE_DROPOUT_APART="1")):
+        assert torch.equal(g0, g1) and torch.equal(s0, s1)
+    for env in (dict(MOPOE_NLL_APART="1"), dict(MOPOE_NN_WIDE="1")):
+        for (g0, s0), (g2, s2) in zip(base_run, run(**env)):
+            assert (g0 - g2).abs().max().item() <= 2e-5 * g0.abs().max().item() + 1e-7, env
+            assert torch.allclose(s0, s2, rtol=2e-5, atol=1e-4), env
+
+
 def _kernel_counts(eng, batches, **kw):
     L.profile_enable(True)
     try:
