@@ -1366,9 +1366,12 @@ constexpr int kWgLd = 36;  // leading dim of a 32x32 partial block in LDS
 // its bias column) is pushed into every peer's inbox at its place in the flat buffer,
 // the block's flag is raised at every peer, the peers' copies are awaited and added in
 // rank order.  The N-rank step then has the same two launches as the one-rank step.
-template <int kWgWaves, bool XG>
-__global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
-                                                         const WArgs w_by_value) {
+// LEAN (eight waves): half rounds only and at most 128 registers, so that TWO blocks share a CU
+// -- for launches with more blocks than CUs (four modalities; the general chain's ten jobs),
+// where the 166-register form needs a second round of blocks
+template <int kWgWaves, bool XG, bool LEAN = false>
+__global__ __launch_bounds__(kWgWaves * 64, LEAN ? 4 : 1) void k_wgrad(const KArgs a_by_value,
+                                                                       const WArgs w_by_value) {
     __shared__ __attribute__((aligned(16))) float blk[kWgWaves][32 * kWgLd];
     (void)a_by_value;  // both argument blocks are read in place (see k_latent)
     (void)w_by_value;
@@ -1476,17 +1479,17 @@ __global__ __launch_bounds__(kWgWaves * 64) void k_wgrad(const KArgs a_by_value,
 #endif
         // (sixteen waves: 128 registers each -- half rounds only, the other waves cover the trips)
         if (th == 16) {   // (only non-gathered operands: the decoder's z and g_xhat)
-            if (half || kWgWaves == 16)
+            if (half || kWgWaves == 16 || LEAN)
                 WG_FOLD(false, 8, 1, false);
             else
                 WG_LONG16(false, 1);
         } else if (job.xrows) {
-            if (half || kWgWaves == 16)
+            if (half || kWgWaves == 16 || LEAN)
                 WG_FOLD(true, 8, 2, false);
             else
                 WG_LONG(true, 2);
         } else {
-            if (half || kWgWaves == 16)
+            if (half || kWgWaves == 16 || LEAN)
                 WG_FOLD(false, 8, 2, false);
             else
                 WG_LONG(false, 2);
@@ -2234,6 +2237,7 @@ struct Knobs {
                          // an encoder without a hidden layer and the logvar head otherwise run in the row-group kernel)
     bool drop_apart;     // MOPOE_DROPOUT_APART: Dropout as a launch of its own behind every hidden layer (A/B)
     bool nll_apart;      // MOPOE_NLL_APART: the likelihood as a launch of its own in a training step (A/B)
+    bool wgrad_lean8;    // MOPOE_WGRAD_LEAN8 (default 1): k_wgrad<8, lean> where the launch has 1-2 blocks per CU
     bool nn_wide;        // MOPOE_NN_WIDE: g_gemm_nn with one wave per tile at every batch size (A/B)
     bool uniform_ks;     // MOPOE_UNIFORM_KS: one K-part count for all wide modalities in the fused launch (A/B)
     int lin_xcd;         // MOPOE_LIN_XCD: k_linear_big's XCD-aware tile order (1)
@@ -2258,6 +2262,7 @@ Knobs read_knobs() {
     k.lin_xcd = num("MOPOE_LIN_XCD", 1);
     k.uniform_ks = getenv("MOPOE_UNIFORM_KS") != nullptr;
     k.nn_wide = getenv("MOPOE_NN_WIDE") != nullptr;
+    k.wgrad_lean8 = num("MOPOE_WGRAD_LEAN8", 1) != 0;
     k.nll_apart = getenv("MOPOE_NLL_APART") != nullptr;
     k.drop_apart = getenv("MOPOE_DROPOUT_APART") != nullptr;
     k.enc0_chain = getenv("MOPOE_TOPOLOGY_CHAIN") != nullptr;
@@ -3155,7 +3160,13 @@ int train_step_impl(const mopoe_model* mdl, const mopoe_step* st, const mopoe_bu
             hipLaunchKernelGGL((k_wgrad<16, false>), grid, dim3(1024), 0, s, ka, w);
         } else
 #endif
-        if (ka.st.n > 512 || (ka.st.n >= 256 && grid.x <= 256)) {
+        // ... and where the launch has MORE blocks than CUs (four modalities: 277; the general
+        // chain's ten jobs: 441) the lean eight-wave form, two blocks to a CU: configs[4] 60.05 ->
+        // 58.8 us per step (k_wgrad 14.5 -> 13.4), the chain at 2 + 1 hidden layers 87.9 -> 86.5
+        if (!comm && g_knobs.wgrad_lean8 && ka.st.n >= 256 && grid.x > (unsigned)device_cus() &&
+            grid.x <= 2u * (unsigned)device_cus()) {
+            hipLaunchKernelGGL((k_wgrad<8, false, true>), grid, dim3(512), 0, s, ka, w);
+        } else if (ka.st.n > 512 || (ka.st.n >= 256 && grid.x <= 256)) {
             if (comm)
                 hipLaunchKernelGGL((k_wgrad<8, true>), grid, dim3(512), 0, s, ka, w);
             else
