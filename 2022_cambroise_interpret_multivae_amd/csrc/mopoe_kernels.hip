@@ -2238,6 +2238,7 @@ struct Knobs {
     bool drop_apart;     // MOPOE_DROPOUT_APART: Dropout as a launch of its own behind every hidden layer (A/B)
     bool nll_apart;      // MOPOE_NLL_APART: the likelihood as a launch of its own in a training step (A/B)
     bool wgrad_lean8;    // MOPOE_WGRAD_LEAN8 (default 1): k_wgrad<8, lean> where the launch has 1-2 blocks per CU
+    bool dec0_apart;     // MOPOE_DEC0_APART: the decoders' first hidden layer as a launch of its own (A/B)
     bool nn_wide;        // MOPOE_NN_WIDE: g_gemm_nn with one wave per tile at every batch size (A/B)
     bool uniform_ks;     // MOPOE_UNIFORM_KS: one K-part count for all wide modalities in the fused launch (A/B)
     int lin_xcd;         // MOPOE_LIN_XCD: k_linear_big's XCD-aware tile order (1)
@@ -2262,6 +2263,7 @@ Knobs read_knobs() {
     k.lin_xcd = num("MOPOE_LIN_XCD", 1);
     k.uniform_ks = getenv("MOPOE_UNIFORM_KS") != nullptr;
     k.nn_wide = getenv("MOPOE_NN_WIDE") != nullptr;
+    k.dec0_apart = getenv("MOPOE_DEC0_APART") != nullptr;
     k.wgrad_lean8 = num("MOPOE_WGRAD_LEAN8", 1) != 0;
     k.nll_apart = getenv("MOPOE_NLL_APART") != nullptr;
     k.drop_apart = getenv("MOPOE_DROPOUT_APART") != nullptr;
