@@ -209,6 +209,53 @@ def test_epilogue_forms_of_the_chain_equal_the_separate_launches(method, base, m
             assert torch.allclose(s0, s2, rtol=2e-5, atol=1e-4), env
 
 
+RANDOM_CHAINS = [
+    # names / input dims / style dims / class dim / method / topology / rows: shapes off the
+    # benchmark's -- z wider than the 48 the fused decoder layer takes, dims that are not multiples
+    # of 4 or 16, one to five modalities, a missing one, partial row tiles
+    dict(dims=[13, 70], style=[0, 30], D=24, method="joint_elbo", topo=dict(enc_layers=2, dec_layers=2, dropout=0.3), n=37),
+    dict(dims=[5, 33, 130], style=[2, 9, 28], D=20, method="joint_elbo", topo=dict(enc_layers=1, dec_layers=1, dropout=0.1), n=200),
+    dict(dims=[444], style=[7], D=16, method="joint_elbo", topo=dict(enc_layers=3, dec_layers=1), n=64),
+    dict(dims=[9, 18, 27, 36, 45], style=[2, 2, 3, 4, 5], D=11, method="joint_elbo",
+         topo=dict(enc_layers=2, dec_layers=1, dropout=0.2), n=48, present=[0, 2, 3]),
+    dict(dims=[21, 260], style=[4, 12], D=20, method="poe", topo=dict(enc_layers=2, dec_layers=1, dropout=0.25), n=96),
+    dict(dims=[21, 260], style=[4, 12], D=20, method="moe", topo=dict(enc_layers=1, dec_layers=2), n=50),
+    dict(dims=[30, 17], style=[40, 3], D=20, method="joint_elbo", topo=dict(enc_layers=1, dec_layers=1, dropout=0.2), n=80),
+]
+
+
+@pytest.mark.parametrize("case", RANDOM_CHAINS, ids=lambda c: "%s-%s-n%d" % (c["method"], "x".join(map(str, c["dims"])), c["n"]))
+def test_chains_of_other_shapes_against_the_oracle(case):
+    """Two training steps of general topologies whose shapes are not the benchmark's, the oracle's
+    eps and dropout keep masks injected, step by step from the engine's own parameters: forward
+    scalars and reconstructions, every gradient, Adam's first moment."""
+    names = ["m%d" % i for i in range(len(case["dims"]))]
+    cfg = mo.Config(names=names, input_dim=case["dims"], style_dim=case["style"], class_dim=case["D"],
+                    method=case["method"], **case["topo"])
+    present = None if "present" not in case else [names[i] for i in case["present"]]
+    spec, eng = make_engine(cfg)
+    assert spec.general
+    rep = Report("chain %s" % case)
+    for step in range(2):
+        x = mo.make_inputs(cfg.names, cfg.input_dim, case["n"], seed=300 + step, present=present)
+        noise = mo.Noise(generator=mo.noise_rng(310 + step), mask_generator=mo.noise_rng(320 + step))
+        params_now = OrderedDict((k, v.cpu().clone()) for k, v in eng.named_params().items())
+        st = {"step": OrderedDict((k, step if present is None or k.split(".")[1] in present else 0)
+                                  for k in params_now),
+              "exp_avg": OrderedDict((k, v.cpu().clone()) for k, v in spec.param_views(eng.exp_avg).items()),
+              "exp_avg_sq": OrderedDict((k, v.cpu().clone()) for k, v in spec.param_views(eng.exp_avg_sq).items())}
+        out, grads = mo.train_step(params_now, cfg, x, noise, st)
+        plan, ws = eng.train_step(x, eps=noise.tape, masks=noise.mask_tape or None)
+        torch.cuda.synchronize()
+        p = "step%d/" % step
+        compare_forward(rep, spec, eng, plan, ws, out, prefix=p, check_scale=False)
+        for k, g in grads.items():
+            rep.close_scaled(p + "grad/" + k, eng.grad_views[k], g, TOL["grad"])
+            rep.close_scaled(p + "exp_avg/" + k, spec.param_views(eng.exp_avg)[k], st["exp_avg"][k], TOL["grad"])
+        eng.check_valid(sync=True)
+    rep.finish()
+
+
 def _kernel_counts(eng, batches, **kw):
     L.profile_enable(True)
     try:
