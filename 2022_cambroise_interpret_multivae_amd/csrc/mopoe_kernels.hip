@@ -499,6 +499,7 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
         if (j0 >= g.ncols) return;   // (wave-uniform)
         const LinNll& nq = *(const LinNll*)ex;
         const LinNllGroup& ng = nq.g[blockIdx.z];
+        if (n0 >= ng.rows) return;   // (the launch's rows are the groups' maximum: not a tile of this modality)
         const int slot = n0 / nq.n_step;          // (a tile lies inside one slot)
         const int g0 = n0 - slot * nq.n_step;     // its first row inside the slot
         float* part = nq.partials + (size_t)(g0 >> 4) * nq.part_stride;
