@@ -13,8 +13,20 @@ eng.reset_parameters(torch.Generator().manual_seed(0))
 g = torch.Generator().manual_seed(1)
 pool = [{"clinical": torch.randn(256, 7, generator=g).cuda(),
          "rois": torch.randn(256, 444, generator=g).cuda()} for _ in range(16)]
+fine = int(sys.argv[2]) if len(sys.argv) > 2 else 10 ** 9     # from this step on: every 10 steps, with the heads
 for i in range(20000):
     plan, ws = eng.train_step(pool[i % 16])
+    if i >= fine and i % 10 == 0:
+        torch.cuda.synchronize()
+        hm = [float(ws.heads[m][:256].abs().max()) for m in range(2)]
+        names = sorted(eng.views, key=lambda k: -float(eng.views[k].abs().max()) if torch.isfinite(eng.views[k]).all() else -1e30)[:2]
+        print("step %5d loss %10.5g  max|heads| %9.4g %9.4g  largest: %s" % (
+            i, float(ws.stats[L.STAT_TOTAL_LOSS]), hm[0], hm[1],
+            ", ".join("%s %.3g" % (k, float(eng.views[k].abs().max())) for k in names)), flush=True)
+        if not torch.isfinite(eng.params).all():
+            bad = [k for k in eng.views if not torch.isfinite(eng.views[k]).all()]
+            print("non-finite:", bad[:8], len(bad))
+            break
     if i % 500 == 0 or i < 3:
         torch.cuda.synchronize()
         loss = float(ws.stats[L.STAT_TOTAL_LOSS])
