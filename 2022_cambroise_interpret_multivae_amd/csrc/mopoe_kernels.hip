@@ -1392,6 +1392,11 @@ __global__ __launch_bounds__(kWgWaves * 64, LEAN ? 4 : 1) void k_wgrad(const KAr
     //  fused launch behind it 1.3 us slower at 1,024 rows (the updated weights then sit in other
     //  XCDs' L2s than the ones its producers run on): profiles/r04_c_ab_k_wgrad_variants.txt.)
     const int b = blockIdx.x;
+#if defined(MOPOE_FENCE_PROBE) && MOPOE_FENCE_PROBE >= 2
+    // (diagnostic build: ... and what the matching acquire would cost every weight-gradient block)
+    if (wave == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+#endif
     const bool fuse = w.fuse_adam != 0;
     const bool stamp_blk = b == 20 && tid == 0;  // a W1 block of the large modality
     (void)stamp_blk;
