@@ -180,12 +180,15 @@ struct LinNllGroup {
     const int32_t* row_index;  // gather (n_step) or nullptr
     const float* lvo;          // (ncols) learnt logvar
     float* g_xhat;             // out (rows, ncols)
+    const float* loc;          // sample scale: the loc head's output (the launch in front), (rows, ncols)
+    float* g_lv;               // sample scale: out, d loss / d logvar (rows, ncols)
     int32_t x_rows, rows;      // rows = slots * n_step of this group
     int32_t lvo_part[kNllSlots], tile_off[kNllSlots];
     float coef[kNllSlots];     // nll_coef / n_step of the slot's job
 };
 struct LinNll {
-    int32_t n_step, laplace, part_stride, pad;   // n_step % 16 == 0 where a modality has two slots
+    int32_t n_step, laplace, part_stride;   // n_step % 16 == 0 where a modality has two slots
+    int32_t sample_scale;      // this launch is the LOGVAR head (learn_output_sample_scale): Y = logvar, loc is read
     float* partials;
     LinNllGroup g[MOPOE_MAX_MODS];
 };
@@ -507,8 +510,9 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
         const bool laplace = nq.laplace != 0, cv = col < g.ncols;
         const int q = lane >> 4, dm = g.ncols;
         const float bias = (g.b && cv) ? g.b[col] : 0.f;
-        const float l = cv ? ng.lvo[col] : 0.f;
-        float xv[4];
+        const bool ss = nq.sample_scale != 0;   // (the logvar head's launch: this tile is logvar, loc is read)
+        const float lcol = (cv && !ss) ? ng.lvo[col] : 0.f;
+        float xv[4], lc[4];
         bool rv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -516,13 +520,17 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
             rv[r] = cv & (gn < nq.n_step) & (n0 + 4 * q + r < ng.rows);
             const int src = ng.row_index ? ng.row_index[rv[r] ? gn : 0] : gn;
             xv[r] = (rv[r] && (unsigned)src < (unsigned)ng.x_rows) ? ng.x[(size_t)src * dm + col] : 0.f;
+            lc[r] = (ss && rv[r]) ? ng.loc[(size_t)(n0 + 4 * q + r) * dm + col] : 0.f;
         }
-        const float inv_var = expf(laplace ? -0.5f * l : -l);
+        const float inv_var_col = expf(laplace ? -0.5f * lcol : -lcol);
         float term = 0.f, glv = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const size_t o = (size_t)(n0 + 4 * q + r) * dm + col;
-            const float loc = acc[r] + bias;
+            const float head = acc[r] + bias;
+            const float loc = ss ? lc[r] : head;
+            const float l = ss ? head : lcol;
+            const float inv_var = ss ? expf(laplace ? -0.5f * l : -l) : inv_var_col;
             const float diff = xv[r] - loc;
             float qq, gg, gl, t;
             if (laplace) {   // scale b = e^(lv / 2): |diff| / b + lv / 2 + log 2
@@ -537,17 +545,18 @@ DEV void linear_tile(const LinArgs& a, const LinGroup& g, float* lds, const int*
                 gg = -diff * inv_var * coef;
             }
             if (rv[r]) {
-                g.Y[o] = loc;   // (ldy == ncols)
+                g.Y[o] = head;   // (ldy == ncols)
                 ng.g_xhat[o] = gg;
+                if (ss) ng.g_lv[o] = gl * coef;
                 term += t;
                 glv += gl;
             }
         }
-        // d loss / d logvar of the group's rows, per column: this lane's four rows + the three
-        // other row quarters of the same column (lanes c + 16, + 32, + 48)
+        // d loss / d logvar of the group's rows, per column (the learnt logvar vector): this lane's
+        // four rows + the three other row quarters of the same column (lanes c + 16, + 32, + 48)
         glv += __shfl_xor(glv, 16);
         glv += __shfl_xor(glv, 32);
-        if (q == 0 && cv) part[(slot == 0 ? ng.lvo_part[0] : ng.lvo_part[1]) + col] = glv * coef;
+        if (q == 0 && cv && !ss) part[(slot == 0 ? ng.lvo_part[0] : ng.lvo_part[1]) + col] = glv * coef;
         const float ts = wave_sum(term);
         if (lane == 0) part[(slot == 0 ? ng.tile_off[0] : ng.tile_off[1]) + (j0 >> 4)] = ts;
         return;
