@@ -221,6 +221,10 @@ RANDOM_CHAINS = [
     dict(dims=[21, 260], style=[4, 12], D=20, method="poe", topo=dict(enc_layers=2, dec_layers=1, dropout=0.25), n=96),
     dict(dims=[21, 260], style=[4, 12], D=20, method="moe", topo=dict(enc_layers=1, dec_layers=2), n=50),
     dict(dims=[30, 17], style=[40, 3], D=20, method="joint_elbo", topo=dict(enc_layers=1, dec_layers=1, dropout=0.2), n=80),
+    # the logvar head (the likelihood on ITS launch): two decoder passes per modality, tile-aligned; one pass, ragged
+    dict(dims=[12, 100], style=[2, 6], D=10, method="poe", topo=dict(enc_layers=1, dec_layers=1, sample_scale=True), n=32),
+    dict(dims=[12, 100, 33], style=[2, 6, 0], D=10, method="joint_elbo",
+         topo=dict(enc_layers=2, dec_layers=2, dropout=0.2, sample_scale=True), n=45),
 ]
 
 
@@ -252,6 +256,10 @@ def test_chains_of_other_shapes_against_the_oracle(case):
         for k, g in grads.items():
             rep.close_scaled(p + "grad/" + k, eng.grad_views[k], g, TOL["grad"])
             rep.close_scaled(p + "exp_avg/" + k, spec.param_views(eng.exp_avg)[k], st["exp_avg"][k], TOL["grad"])
+        if cfg.sample_scale:    # the head's (N, d) scale of THIS forward
+            res = eng.results(plan, ws)
+            for k in res["rec"]:
+                rep.close(p + "rec/%s/scale" % k, res["rec"][k].scale, out["results"]["rec"][k][1], 2e-5, 1e-6)
         eng.check_valid(sync=True)
     rep.finish()
 

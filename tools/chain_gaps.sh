@@ -17,7 +17,8 @@ rows = [r for r in rows if short(r).startswith(("k_", "g_"))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # one step = from a kernel after k_wgrad to the next k_wgrad; take the step pattern from the tail
 names = [short(r) for r in rows]
-ends = [i for i, n in enumerate(names) if n.startswith("k_wgrad")]
+# (a step ends with its LAST weight-gradient launch: more than fifteen jobs take two)
+ends = [i for i, n in enumerate(names) if n.startswith("k_wgrad") and not (i + 1 < len(names) and names[i + 1].startswith("k_wgrad"))]
 per = ends[-1] - ends[-2]
 print("launches per step:", per)
 first = ends[-200] + 1
