@@ -78,6 +78,37 @@ def test_index_batches_equal_materialised_batches():
     assert seen == {("clinical",), ("rois",), ("clinical", "rois")}
 
 
+@pytest.mark.parametrize("topo", [dict(enc_layers=2, dec_layers=1, dropout=0.2), dict(enc_layers=1, dec_layers=1, sample_scale=True)],
+                         ids=["enc2-dec1-drop", "dec1-logvar-head"])
+def test_index_batches_through_the_general_chain(topo):
+    """The same over a general topology's chain of launches (its first layer and the likelihood in
+    the output layer's epilogue read x through the row index): a step on index batches over the
+    resident blocks equals the step on the gathered copy bit for bit -- gradients, scalars,
+    parameters -- complete and missing-modality batches alike."""
+    ds = synthetic_cohort()
+    cohort = ds_mod.ResidentCohort(ds, "cuda")
+    cfg = mo.Config(["clinical", "rois"], [7, 444], [3, 20], **topo)
+    import mopoe_amd as mm
+    spec, _ = make_engine(cfg)
+    eng_a, eng_b = mm.MoPoEEngine(spec, "cuda", seed=11), mm.MoPoEEngine(spec, "cuda", seed=11)
+    for e in (eng_a, eng_b):
+        e.load_params(mo.init_params(cfg, 0))
+    np.random.seed(5)
+    seen = set()
+    for k, b in enumerate(ds_mod.MissingModalitySampler(ds, 48)):
+        inputs, row_index = cohort.batch(b)
+        seen.add(tuple(inputs))
+        gathered = OrderedDict((m, cohort.x[m][row_index[m].long().cuda()]) for m in inputs)
+        _, ws_a = eng_a.train_step(inputs, row_index=row_index)     # (device-drawn noise and masks: same seed)
+        _, ws_b = eng_b.train_step(gathered)
+        torch.cuda.synchronize()
+        assert torch.equal(ws_a.stats, ws_b.stats), k
+        assert torch.equal(eng_a.grads, eng_b.grads), k
+    eng_a.check_valid(sync=True)
+    assert torch.equal(eng_a.params, eng_b.params)
+    assert seen == {("clinical",), ("rois",), ("clinical", "rois")}
+
+
 def test_train_epoch_over_resident_cohort():
     cfg = mo.Config(["clinical", "rois"], [7, 444], [3, 20])
     exp = make_experiment(cfg, "cuda")
